@@ -1,0 +1,149 @@
+/*
+ * pybmc_amd.h -- C ABI of the MI355X-native Gibbs-sampling core for Bayesian
+ * model combination (libpybmc_amd.so, gfx950 only).
+ *
+ * The reference (sudhanvalalit/pybmc) has no FFI: its boundary is three Python
+ * call signatures.  Each entry point below names the reference interface it
+ * replaces (file:line in the reference checkout).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every HOST buffer is caller-owned, is read
+ *     or written only during the call and is never retained;
+ *   - every function returns a bmc_status (0 = OK); no exception, abort or
+ *     longjmp crosses the ABI; bmc_last_error() gives the text;
+ *   - a bmc_ctx belongs to one GPU and is driven by one host thread at a time;
+ *     distinct contexts are independent (no global mutable state);
+ *   - there is NO CPU fallback: without a usable gfx950 device bmc_create fails.
+ */
+#ifndef PYBMC_AMD_H
+#define PYBMC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYBMC_AMD_ABI_VERSION 1
+
+typedef struct bmc_ctx bmc_ctx;
+
+typedef enum {
+    BMC_OK = 0,
+    BMC_EINVAL = 1,    /* bad argument            -> Python ValueError            */
+    BMC_ESINGULAR = 2, /* singular C0 or X'X      -> numpy.linalg.LinAlgError     */
+    BMC_EHIP = 3,      /* HIP runtime error       -> RuntimeError                 */
+    BMC_ENOMEM = 4,    /* allocation failed       -> MemoryError                  */
+    BMC_ETIMEOUT = 5,  /* bounded device spin expired (persistent kernel)         */
+    BMC_ESTATE = 6     /* call order violated (e.g. run before set_prior)         */
+} bmc_status;
+
+enum { BMC_F64 = 0, BMC_F32 = 1 };           /* storage type of X and y        */
+enum { BMC_ROW_MAJOR = 0, BMC_COL_MAJOR = 1 }; /* 1 = what U_hat is (F-order) */
+enum { BMC_RNG_DEVICE = 0, BMC_RNG_REPLAY = 1 };
+
+/* Launch geometry knobs (0 = let the library choose). */
+typedef struct {
+    int32_t groups_per_chain; /* workgroups that share one chain's rows        */
+    int32_t waves_per_group;  /* 1..16 (workgroup = 64 * waves threads)        */
+    int32_t force_streaming;  /* 1 = never pin the panels in LDS               */
+    int32_t chains_per_pass;  /* chains served by one read of X (1,2,4,8)      */
+} bmc_tuning;
+
+/* Filled by bmc_gibbs_run*.  Times are HIP-event times on the context's stream. */
+typedef struct {
+    double loop_ms;           /* the persistent Gibbs kernel(s) only           */
+    double rng_ms;            /* variate generation kernels (device RNG mode)  */
+    double post_ms;           /* un-rotation of the draws into beta            */
+    double total_ms;          /* first launch -> last kernel done              */
+    int64_t iterations;       /* per chain                                     */
+    int32_t n_chains;
+    int32_t launches;         /* persistent-kernel launches (chain batches)    */
+    int32_t groups_per_chain;
+    int32_t waves_per_group;
+    int32_t chains_per_pass;
+    int32_t lds_resident;     /* 1 = row panels pinned in LDS for the run      */
+    int64_t bytes_per_pass;   /* algorithmic: (N*K + N) * sizeof(storage)      */
+    int64_t passes;           /* X passes executed in total                    */
+} bmc_stats;
+
+/* ---- lifetime --------------------------------------------------------- */
+int bmc_abi_version(void);
+int bmc_create(int device_id, bmc_ctx** out);
+void bmc_destroy(bmc_ctx* ctx);
+const char* bmc_last_error(const bmc_ctx* ctx);     /* valid until next call  */
+/* Use an existing HIP stream (e.g. torch's current stream); NULL = own stream. */
+int bmc_set_stream(bmc_ctx* ctx, void* hip_stream);
+int bmc_set_tuning(bmc_ctx* ctx, const bmc_tuning* t);
+
+/* ---- problem: y (n,), X (n,k) ----------------------------------------------
+ * Replaces the (y, X) arguments of gibbs_sampler, pybmc/inference_utils.py:4,
+ * as passed by BayesianModelCombination.train, pybmc/bmc.py:188-193.
+ * Element (i,j) of X is at X[i*ldx + j] (row-major) or X[i + j*ldx] (col-major,
+ * the layout U_hat has after inference_utils.py:164).  On return the device
+ * holds X, y, and the augmented Gram [X y]'[X y] (inference_utils.py:25 and the
+ * loop-invariant X'y of :43), computed with f64 MFMA.
+ * bmc_set_problem_device takes DEVICE pointers (same layouts). */
+int bmc_set_problem(bmc_ctx* ctx, const void* X, int64_t n, int32_t k, int64_t ldx,
+                    int layout, const void* y, int dtype);
+int bmc_set_problem_device(bmc_ctx* ctx, const void* dX, int64_t n, int32_t k,
+                           int64_t ldx, int layout, const void* dy, int dtype);
+
+/* ---- prior: prior_info = [b0 (k,), C0 (k,k row-major), nu0, sigma20] --------
+ * Replaces inference_utils.py:21-37: P = inv(C0) (:22), inv(X'X) and the OLS
+ * start value sigma2_0 = max(mean r^2, 1e-6) (:26-37).  Also builds the
+ * per-problem basis used by the device loop (DESIGN.md "rotated draw"):
+ *   B = P + 1e-6 I = L L',  L^-1 X'X L^-T = Q diag(lam) Q',  W = L^-T Q,
+ * so that inv(X'X/s2 + P + 1e-6 I) = W diag(1/(lam/s2 + 1)) W'  (:41).
+ * BMC_ESINGULAR when C0 or X'X is singular (numpy raises LinAlgError there). */
+int bmc_set_prior(bmc_ctx* ctx, const double* b0, const double* C0, double nu0,
+                  double sigma20);
+
+/* ---- introspection used by the parity tests -------------------------------
+ * gram: (k+1)x(k+1) row-major [X y]'[X y].  basis: W (k,k row-major), lam (k,),
+ * sigma2_init.  moments: mean (k,), cov (k,k) of beta | sigma2 (:41-44). */
+int bmc_get_gram(bmc_ctx* ctx, double* gram_out);
+int bmc_get_basis(bmc_ctx* ctx, double* W_out, double* lam_out, double* sigma2_init);
+int bmc_conditional_moments(bmc_ctx* ctx, double sigma2, double* mean_out,
+                            double* cov_out);
+
+/* ---- residual reduction: rss[b] = sum_i (y_i - sum_j X_ij beta[b][j])^2 -------
+ * Replaces inference_utils.py:48-51 as a stand-alone streaming kernel over the
+ * un-rotated X (nb coefficient vectors share one pass over X). */
+int bmc_residual_rss(bmc_ctx* ctx, const double* beta, int32_t nb, double* rss_out);
+/* Same kernel launched `reps` times back to back on data already in HBM; returns
+ * the HIP-event time per launch.  Roofline measurement only. */
+int bmc_residual_rss_bench(bmc_ctx* ctx, int32_t nb, int32_t reps, double* ms_per_launch);
+
+/* ---- the Gibbs loop ---------------------------------------------------------
+ * Replaces the loop of gibbs_sampler, pybmc/inference_utils.py:39-56, for
+ * n_chains independent chains.  samples_out is [n_chains][iters][k+1] f64,
+ * row t = [beta_t (k), sigma_t = sqrt(sigma2_t)]  (:54).
+ * rng_mode BMC_RNG_DEVICE: seeds[n_chains]; variates from the on-device Philox
+ *   generator (xi, g must be NULL).
+ * rng_mode BMC_RNG_REPLAY: xi [n_chains][iters][k] standard-normal innovations
+ *   in the basis of bmc_get_basis, g [n_chains][iters] Gamma((nu0+n)/2, 1)
+ *   variates (seeds may be NULL).  Used to replay the reference's chain.
+ * bmc_gibbs_run_device is the device-RNG form writing to a caller-owned DEVICE
+ * buffer (no device->host copy of the samples); it returns after the stream has
+ * drained so that the status words and the event times in `stats` are final. */
+int bmc_gibbs_run(bmc_ctx* ctx, int32_t n_chains, int64_t iters, const uint64_t* seeds,
+                  int rng_mode, const double* xi, const double* g, double* samples_out,
+                  bmc_stats* stats);
+int bmc_gibbs_run_device(bmc_ctx* ctx, int32_t n_chains, int64_t iters,
+                         const uint64_t* seeds, void* d_samples_out, bmc_stats* stats);
+
+/* ---- on-device variates (exposed so the generator itself can be tested) ----
+ * normals_out [count_normal] ~ N(0,1); gammas_out [count_gamma] ~ Gamma(shape,1). */
+int bmc_rng_fill(bmc_ctx* ctx, uint64_t seed, int64_t count_normal, double* normals_out,
+                 double shape, int64_t count_gamma, double* gammas_out);
+/* Raw Philox4x32-10 blocks: out[4*i..4*i+3] = philox(counter = (i_lo, i_hi, stream_id, 0),
+ * key = seed) for i < nblocks4.  Integer output, checked bit-for-bit by the tests. */
+int bmc_philox_raw(bmc_ctx* ctx, uint64_t seed, uint32_t stream_id, int64_t nblocks4,
+                   uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYBMC_AMD_H */

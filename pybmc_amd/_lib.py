@@ -1,0 +1,269 @@
+"""ctypes binding of libpybmc_amd.so (the C ABI declared in include/pybmc_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 GPU is
+usable, the calls raise.  Status codes are mapped back to the exception types the
+reference raises at the same places (numpy ``LinAlgError`` for singular matrices,
+``ValueError`` for bad arguments).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpybmc_amd.so")
+
+BMC_OK, BMC_EINVAL, BMC_ESINGULAR, BMC_EHIP, BMC_ENOMEM, BMC_ETIMEOUT, BMC_ESTATE = range(7)
+BMC_F64, BMC_F32 = 0, 1
+BMC_ROW_MAJOR, BMC_COL_MAJOR = 0, 1
+BMC_RNG_DEVICE, BMC_RNG_REPLAY = 0, 1
+
+
+class Tuning(C.Structure):
+    _fields_ = [("groups_per_chain", C.c_int32), ("waves_per_group", C.c_int32),
+                ("force_streaming", C.c_int32), ("chains_per_pass", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("loop_ms", C.c_double), ("rng_ms", C.c_double), ("post_ms", C.c_double),
+                ("total_ms", C.c_double), ("iterations", C.c_int64), ("n_chains", C.c_int32),
+                ("launches", C.c_int32), ("groups_per_chain", C.c_int32),
+                ("waves_per_group", C.c_int32), ("chains_per_pass", C.c_int32),
+                ("lds_resident", C.c_int32), ("bytes_per_pass", C.c_int64),
+                ("passes", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# name -> (restype, argtypes); every symbol include/pybmc_amd.h declares
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+PROTOTYPES = {
+    "bmc_abi_version": (C.c_int, []),
+    "bmc_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "bmc_destroy": (None, [_P]),
+    "bmc_last_error": (C.c_char_p, [_P]),
+    "bmc_set_stream": (C.c_int, [_P, _P]),
+    "bmc_set_tuning": (C.c_int, [_P, C.POINTER(Tuning)]),
+    "bmc_set_problem": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int, _P, C.c_int]),
+    "bmc_set_problem_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int, _P,
+                                         C.c_int]),
+    "bmc_set_prior": (C.c_int, [_P, _D, _D, C.c_double, C.c_double]),
+    "bmc_get_gram": (C.c_int, [_P, _D]),
+    "bmc_get_basis": (C.c_int, [_P, _D, _D, _D]),
+    "bmc_conditional_moments": (C.c_int, [_P, C.c_double, _D, _D]),
+    "bmc_residual_rss": (C.c_int, [_P, _D, C.c_int32, _D]),
+    "bmc_residual_rss_bench": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
+    "bmc_gibbs_run": (C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_uint64), C.c_int, _D, _D,
+                                _D, C.POINTER(Stats)]),
+    "bmc_gibbs_run_device": (C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_uint64), _P,
+                                       C.POINTER(Stats)]),
+    "bmc_rng_fill": (C.c_int, [_P, C.c_uint64, C.c_int64, _D, C.c_double, C.c_int64, _D]),
+    "bmc_philox_raw": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(C.c_uint32)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen the in-tree library and bind every prototype.  Raises if absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C pybmc_amd/csrc` "
+                "(or __graft_entry__.build()).  pybmc_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.bmc_abi_version() != 1:
+            raise RuntimeError("libpybmc_amd.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_D) if a is not None else None
+
+
+class BmcError(RuntimeError):
+    pass
+
+
+class Context:
+    """One bmc_ctx: one GPU, one host thread at a time."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = _P()
+        rc = self._lib.bmc_create(int(device), C.byref(h))
+        if rc != BMC_OK:
+            raise BmcError(
+                f"bmc_create(device={device}) failed with status {rc}: no usable gfx950 "
+                "(MI355X) device.  pybmc_amd has no CPU fallback.")
+        self._h = h
+        self.device = int(device)
+        self.n = self.k = 0
+
+    # -- plumbing --------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == BMC_OK:
+            return
+        msg = (self._lib.bmc_last_error(self._h) or b"").decode("utf-8", "replace")
+        if rc == BMC_ESINGULAR:
+            raise np.linalg.LinAlgError(msg or "Singular matrix")
+        if rc == BMC_EINVAL:
+            raise ValueError(msg)
+        if rc == BMC_ENOMEM:
+            raise MemoryError(msg)
+        raise BmcError(f"status {rc}: {msg}")
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.bmc_set_stream(self._h, _P(hip_stream_ptr or 0)))
+
+    def set_tuning(self, groups_per_chain=0, waves_per_group=0, force_streaming=0,
+                   chains_per_pass=0):
+        t = Tuning(groups_per_chain, waves_per_group, force_streaming, chains_per_pass)
+        self._check(self._lib.bmc_set_tuning(self._h, C.byref(t)))
+
+    # -- problem / prior ---------------------------------------------------------
+    def set_problem(self, y, X, dtype=None):
+        """y (n,), X (n,k).  Keeps X's own memory order when it is C- or F-contiguous."""
+        X = np.asarray(X)
+        y = np.asarray(y)
+        if X.ndim != 2 or y.ndim != 1 or X.shape[0] != y.shape[0]:
+            raise ValueError("X must be (n, k) and y (n,)")
+        if dtype is None:
+            dtype = np.float32 if (X.dtype == np.float32 and y.dtype == np.float32) else np.float64
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        if X.flags.f_contiguous and not X.flags.c_contiguous:
+            Xc = np.asfortranarray(X, dtype=dtype)
+            layout, ldx = BMC_COL_MAJOR, X.shape[0]
+        else:
+            Xc = np.ascontiguousarray(X, dtype=dtype)
+            layout, ldx = BMC_ROW_MAJOR, X.shape[1]
+        yc = np.ascontiguousarray(y, dtype=dtype)
+        n, k = X.shape
+        self._check(self._lib.bmc_set_problem(
+            self._h, Xc.ctypes.data_as(_P), n, k, max(ldx, 1), layout, yc.ctypes.data_as(_P),
+            BMC_F32 if dtype == np.float32 else BMC_F64))
+        self.n, self.k = n, k
+
+    def set_problem_device(self, x_ptr, n, k, ldx, layout, y_ptr, f32=False):
+        self._check(self._lib.bmc_set_problem_device(
+            self._h, _P(x_ptr), n, k, ldx, layout, _P(y_ptr), BMC_F32 if f32 else BMC_F64))
+        self.n, self.k = n, k
+
+    def set_prior(self, b0, C0, nu0, sigma20):
+        b0 = np.ascontiguousarray(b0, dtype=np.float64).reshape(-1)
+        C0 = np.ascontiguousarray(C0, dtype=np.float64)
+        if b0.shape[0] != self.k or C0.shape != (self.k, self.k):
+            raise ValueError("prior shapes do not match the design matrix")
+        self._check(self._lib.bmc_set_prior(self._h, _dptr(b0), _dptr(C0), float(nu0),
+                                            float(sigma20)))
+
+    # -- introspection -------------------------------------------------------------
+    def gram(self):
+        out = np.empty((self.k + 1, self.k + 1))
+        self._check(self._lib.bmc_get_gram(self._h, _dptr(out)))
+        return out
+
+    def basis(self):
+        W = np.empty((self.k, self.k))
+        lam = np.empty(self.k)
+        s2 = C.c_double()
+        self._check(self._lib.bmc_get_basis(self._h, _dptr(W), _dptr(lam), C.byref(s2)))
+        return W, lam, s2.value
+
+    def conditional_moments(self, sigma2):
+        mean = np.empty(self.k)
+        cov = np.empty((self.k, self.k))
+        self._check(self._lib.bmc_conditional_moments(self._h, float(sigma2), _dptr(mean),
+                                                      _dptr(cov)))
+        return mean, cov
+
+    def residual_rss(self, beta):
+        beta = np.ascontiguousarray(np.atleast_2d(beta), dtype=np.float64)
+        if beta.shape[1] != self.k:
+            raise ValueError("beta must have k columns")
+        out = np.empty(beta.shape[0])
+        self._check(self._lib.bmc_residual_rss(self._h, _dptr(beta), beta.shape[0], _dptr(out)))
+        return out
+
+    def residual_rss_bench(self, nb=1, reps=20):
+        ms = C.c_double()
+        self._check(self._lib.bmc_residual_rss_bench(self._h, nb, reps, C.byref(ms)))
+        return ms.value
+
+    # -- the loop --------------------------------------------------------------------
+    def gibbs_run(self, n_chains, iters, seeds=None, xi=None, g=None):
+        """Returns (samples [n_chains, iters, k+1], stats dict)."""
+        out = np.empty((n_chains, iters, self.k + 1))
+        st = Stats()
+        if xi is not None or g is not None:
+            xi = np.ascontiguousarray(xi, dtype=np.float64).reshape(n_chains, iters, self.k)
+            g = np.ascontiguousarray(g, dtype=np.float64).reshape(n_chains, iters)
+            rc = self._lib.bmc_gibbs_run(self._h, n_chains, iters, None, BMC_RNG_REPLAY,
+                                         _dptr(xi), _dptr(g), _dptr(out), C.byref(st))
+        else:
+            sd = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(n_chains)
+            rc = self._lib.bmc_gibbs_run(self._h, n_chains, iters,
+                                         sd.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         BMC_RNG_DEVICE, None, None, _dptr(out), C.byref(st))
+        self._check(rc)
+        return out, st.as_dict()
+
+    def gibbs_run_device(self, n_chains, iters, seeds, out_ptr):
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(n_chains)
+        st = Stats()
+        self._check(self._lib.bmc_gibbs_run_device(
+            self._h, n_chains, iters, sd.ctypes.data_as(C.POINTER(C.c_uint64)), _P(out_ptr),
+            C.byref(st)))
+        return st.as_dict()
+
+    # -- variates -----------------------------------------------------------------------
+    def rng_fill(self, seed, n_normal=0, shape=1.0, n_gamma=0):
+        z = np.empty(n_normal)
+        g = np.empty(n_gamma)
+        self._check(self._lib.bmc_rng_fill(self._h, int(seed), n_normal, _dptr(z), float(shape),
+                                           n_gamma, _dptr(g)))
+        return z, g
+
+    def philox_raw(self, seed, stream_id, nblocks4):
+        out = np.empty(4 * nblocks4, dtype=np.uint32)
+        self._check(self._lib.bmc_philox_raw(self._h, int(seed), int(stream_id), nblocks4,
+                                             out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out.reshape(nblocks4, 4)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """A cached per-device context for the functional API."""
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

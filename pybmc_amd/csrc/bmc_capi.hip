@@ -1,0 +1,675 @@
+// C ABI of libpybmc_amd.so (see include/pybmc_amd.h).  Host orchestration only:
+// every O(N) step is a gfx950 kernel; the host does the one-off K x K algebra.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pybmc_amd.h"
+#include "bmc_launch.h"
+#include "host_linalg.hpp"
+
+using namespace bmc;
+
+namespace {
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr int MAX_GROUPS_PER_LAUNCH = 256;  // one resident workgroup per CU
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct bmc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bmc_tuning tune{0, 0, 0, 0};
+    int n_cu = 256;
+
+    // problem
+    bool have_problem = false, have_prior = false;
+    int64_t n = 0;
+    int32_t k = 0, vec = 1, npanels = 0, f32 = 0;
+    DevBuf Xraw, Yp, Xrot;
+    std::vector<double> gram;
+
+    // prior / basis (host copies)
+    std::vector<double> W, lam, c1, c2, b0;
+    double nu0 = 0, s20 = 0, sigma2_init = 0;
+    DevBuf dW, dWT, dLam, dC1, dC2;
+
+    // scratch
+    DevBuf gramScratch, gramOut, rssPartial, rssOut, coef, stage;
+    // run buffers
+    DevBuf xi, gam, uout, samples, gran, status, seeds;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int fail(bmc_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                              \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess)                                                         \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? BMC_ENOMEM : BMC_EHIP,       \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));           \
+    } while (0)
+
+int ensure(bmc_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return BMC_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return BMC_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+Panels panels_of(const bmc_ctx* c, const void* X) {
+    Panels P;
+    P.X = X;
+    P.y = c->Yp.p;
+    P.n = c->n;
+    P.k = c->k;
+    P.vec = c->vec;
+    P.npanels = c->npanels;
+    P.f32 = c->f32;
+    return P;
+}
+
+// rows per lane: wide (16-byte) reads once there are enough panels to occupy the
+// chip; narrower panels for small N so that more waves share one pass.
+int choose_vec(int64_t n, int f32) {
+    int vec = f32 ? 4 : 2;
+    while (vec > 1 && (n + 64 * vec - 1) / (64 * vec) < 1024) vec >>= 1;
+    return vec;
+}
+
+int set_problem_common(bmc_ctx* c, const void* dX, const void* dy, int64_t n, int32_t k,
+                       int64_t ldx, int layout, int dtype) {
+    c->have_problem = c->have_prior = false;
+    c->n = n;
+    c->k = k;
+    c->f32 = dtype == BMC_F32;
+    c->vec = choose_vec(n, c->f32);
+    const int RP = 64 * c->vec;
+    c->npanels = (int32_t)((n + RP - 1) / RP);
+    const size_t es = c->f32 ? 4 : 8;
+    int rc;
+    if ((rc = ensure(c, c->Xraw, (size_t)c->npanels * k * RP * es))) return rc;
+    if ((rc = ensure(c, c->Xrot, (size_t)c->npanels * k * RP * es))) return rc;
+    if ((rc = ensure(c, c->Yp, (size_t)c->npanels * RP * es))) return rc;
+    HIPCHK(c, launch_panelize(dX, dy, n, k, ldx, layout == BMC_COL_MAJOR, c->f32, c->vec,
+                              c->Xraw.p, c->Yp.p, c->npanels, c->stream));
+    const Panels P = panels_of(c, c->Xraw.p);
+    if ((rc = ensure(c, c->gramScratch, gram_scratch_bytes(P)))) return rc;
+    const size_t gsz = (size_t)(k + 1) * (k + 1);
+    if ((rc = ensure(c, c->gramOut, gsz * 8))) return rc;
+    HIPCHK(c, launch_gram(P, c->gramScratch.p, (double*)c->gramOut.p, c->stream));
+    c->gram.assign(gsz, 0.0);
+    HIPCHK(c, hipMemcpyAsync(c->gram.data(), c->gramOut.p, gsz * 8, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_problem = true;
+    return BMC_OK;
+}
+
+int check_problem_args(bmc_ctx* c, const void* X, int64_t n, int32_t k, int64_t ldx, int layout,
+                       const void* y, int dtype) {
+    if (!c) return BMC_EINVAL;
+    if (!X || !y) return fail(c, BMC_EINVAL, "X and y must not be NULL");
+    if (n < 1 || k < 1) return fail(c, BMC_EINVAL, "need n >= 1 and k >= 1");
+    if (k > 256) return fail(c, BMC_EINVAL, "k > 256 columns is not supported");
+    if (dtype != BMC_F64 && dtype != BMC_F32) return fail(c, BMC_EINVAL, "dtype must be 0 or 1");
+    if (layout != BMC_ROW_MAJOR && layout != BMC_COL_MAJOR)
+        return fail(c, BMC_EINVAL, "layout must be 0 (row-major) or 1 (col-major)");
+    if (layout == BMC_ROW_MAJOR ? ldx < k : ldx < n)
+        return fail(c, BMC_EINVAL, "leading dimension too small");
+    return BMC_OK;
+}
+
+int rss_on_raw(bmc_ctx* c, const double* coef_host, int32_t nb, double* out_host) {
+    const Panels P = panels_of(c, c->Xraw.p);
+    int rc;
+    if ((rc = ensure(c, c->rssPartial, (size_t)rss_groups(P) * 8 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->rssOut, 8 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->coef, (size_t)8 * c->k * sizeof(double)))) return rc;
+    for (int32_t b0 = 0; b0 < nb; b0 += 8) {
+        const int32_t m = nb - b0 < 8 ? nb - b0 : 8;
+        HIPCHK(c, hipMemcpyAsync(c->coef.p, coef_host + (size_t)b0 * c->k,
+                                 (size_t)m * c->k * sizeof(double), hipMemcpyHostToDevice,
+                                 c->stream));
+        HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p, m, (double*)c->rssPartial.p,
+                                      (double*)c->rssOut.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_host + b0, c->rssOut.p, (size_t)m * sizeof(double),
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return BMC_OK;
+}
+
+struct Geometry {
+    int chains_per_launch, G, waves, ppg, resident;
+};
+
+// Pick the launch geometry: as many chains per launch as stay LDS-resident with
+// one workgroup per CU; ~4 waves per workgroup.
+Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
+    const int RP = 64 * c->vec;
+    const size_t es = c->f32 ? 4 : 8;
+    const size_t panel_bytes = (size_t)(c->k + 1) * RP * es;
+    const size_t fixed = (size_t)((c->k + 2) / 2 * 2) * 8 * 4 + 20 * 8 + 64;
+    const int NP = c->npanels;
+    auto resident_at = [&](int G) {
+        const int ppg = (NP + G - 1) / G;
+        return fixed + (size_t)ppg * panel_bytes <= LDS_LIMIT;
+    };
+    Geometry g{};
+    const int t_waves = c->tune.waves_per_group;
+    if (c->tune.groups_per_chain > 0) {
+        g.G = c->tune.groups_per_chain;
+        if (g.G > MAX_GROUPS_PER_LAUNCH) g.G = MAX_GROUPS_PER_LAUNCH;
+        g.chains_per_launch = MAX_GROUPS_PER_LAUNCH / g.G;
+        if (g.chains_per_launch > n_chains) g.chains_per_launch = n_chains;
+        if (g.chains_per_launch < 1) g.chains_per_launch = 1;
+    } else {
+        int cpl = n_chains < 8 ? n_chains : 8;
+        // fewer chains per launch until the panels fit in LDS (or one chain is left)
+        while (cpl > 1 && !resident_at(MAX_GROUPS_PER_LAUNCH / cpl)) --cpl;
+        g.chains_per_launch = cpl;
+        const int gmax = MAX_GROUPS_PER_LAUNCH / cpl;
+        const int want_waves = t_waves > 0 ? t_waves : 4;
+        int G = (NP + want_waves - 1) / want_waves;  // ~want_waves panels per group
+        if (G > gmax) G = gmax;
+        if (G < 1) G = 1;
+        if (!resident_at(G) && resident_at(gmax)) {
+            while (!resident_at(G)) ++G;
+        }
+        g.G = G;
+    }
+    if (g.G > NP) g.G = NP;
+    g.ppg = (NP + g.G - 1) / g.G;
+    g.resident = !c->tune.force_streaming && resident_at(g.G);
+    int waves = t_waves > 0 ? t_waves : (g.ppg < 4 ? g.ppg : (g.resident ? (g.ppg < 8 ? g.ppg : 8) : 8));
+    if (waves > 16) waves = 16;
+    if (waves < 1) waves = 1;
+    g.waves = waves;
+    return g;
+}
+
+int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seeds, int rng_mode,
+               const double* xi, const double* g, double* samples_host, void* samples_dev,
+               bmc_stats* stats) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_problem || !c->have_prior)
+        return fail(c, BMC_ESTATE, "bmc_set_problem and bmc_set_prior must be called first");
+    if (n_chains < 1 || iters < 0) return fail(c, BMC_EINVAL, "need n_chains >= 1, iters >= 0");
+    if (iters >= 0xffffffffll) return fail(c, BMC_EINVAL, "iters must be < 2^32 - 1");
+    if (rng_mode == BMC_RNG_DEVICE) {
+        if (!seeds) return fail(c, BMC_EINVAL, "seeds required in device RNG mode");
+        if (xi || g) return fail(c, BMC_EINVAL, "xi/g must be NULL in device RNG mode");
+    } else if (rng_mode == BMC_RNG_REPLAY) {
+        if (!xi || !g) return fail(c, BMC_EINVAL, "xi and g required in replay mode");
+    } else {
+        return fail(c, BMC_EINVAL, "rng_mode must be 0 or 1");
+    }
+    const int K = c->k;
+    const size_t T = (size_t)iters, C = (size_t)n_chains;
+    int rc;
+    if ((rc = ensure(c, c->xi, C * T * K * 8))) return rc;
+    if ((rc = ensure(c, c->gam, C * T * 8))) return rc;
+    if ((rc = ensure(c, c->uout, C * T * (K + 1) * 8))) return rc;
+    double* d_samples = (double*)samples_dev;
+    if (!d_samples) {
+        if ((rc = ensure(c, c->samples, C * T * (K + 1) * 8))) return rc;
+        d_samples = (double*)c->samples.p;
+    }
+    const Geometry geo = choose_geometry(c, n_chains);
+    const int gran_stride = ((2 * geo.G + 31) / 32) * 32;
+    if ((rc = ensure(c, c->gran, (size_t)geo.chains_per_launch * 2 * gran_stride * 8))) return rc;
+    if ((rc = ensure(c, c->status, C * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->seeds, C * sizeof(uint64_t)))) return rc;
+
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, C * sizeof(int32_t), c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (iters > 0) {
+        if (rng_mode == BMC_RNG_DEVICE) {
+            HIPCHK(c, hipMemcpyAsync(c->seeds.p, seeds, C * sizeof(uint64_t),
+                                     hipMemcpyHostToDevice, c->stream));
+            const double shape = (c->nu0 + (double)c->n) / 2.0;  // inference_utils.py:50
+            HIPCHK(c, launch_rng_fill((const uint64_t*)c->seeds.p, n_chains, (int64_t)T * K,
+                                      (double*)c->xi.p, shape, (int64_t)T, (double*)c->gam.p,
+                                      c->stream));
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->xi.p, xi, C * T * K * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->gam.p, g, C * T * 8, hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+
+    GibbsArgs a;
+    a.P = panels_of(c, c->Xrot.p);
+    a.lam = (const double*)c->dLam.p;
+    a.c1 = (const double*)c->dC1.p;
+    a.c2 = (const double*)c->dC2.p;
+    a.nu0_s20 = c->nu0 * c->s20;
+    a.sigma2_init = c->sigma2_init;
+    a.gran = (unsigned long long*)c->gran.p;
+    a.gran_stride = gran_stride;
+    a.iters = iters;
+    a.G = geo.G;
+    a.waves = geo.waves;
+    a.resident = geo.resident;
+    a.panels_per_group = geo.ppg;
+    int launches = 0;
+    for (int c0 = 0; iters > 0 && c0 < n_chains; c0 += geo.chains_per_launch) {
+        const int m = n_chains - c0 < geo.chains_per_launch ? n_chains - c0 : geo.chains_per_launch;
+        a.n_chains = m;
+        a.xi = (const double*)c->xi.p + (size_t)c0 * T * K;
+        a.gam = (const double*)c->gam.p + (size_t)c0 * T;
+        a.uout = (double*)c->uout.p + (size_t)c0 * T * (K + 1);
+        a.status = (int32_t*)c->status.p + c0;
+        HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)m * 2 * gran_stride * 8, c->stream));
+        if (gibbs_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
+        HIPCHK(c, launch_gibbs(a, c->stream));
+        ++launches;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (iters > 0)
+        HIPCHK(c, launch_unrotate((const double*)c->uout.p, (const double*)c->dWT.p, K,
+                                  (int64_t)(C * T), d_samples, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    std::vector<int32_t> st(C, 0);
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, C * sizeof(int32_t), hipMemcpyDeviceToHost,
+                             c->stream));
+    if (samples_host && iters > 0)
+        HIPCHK(c, hipMemcpyAsync(samples_host, d_samples, C * T * (K + 1) * 8,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stats) {
+        float ms = 0;
+        std::memset(stats, 0, sizeof(*stats));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); stats->rng_ms = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); stats->loop_ms = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); stats->post_ms = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); stats->total_ms = ms;
+        stats->iterations = iters;
+        stats->n_chains = n_chains;
+        stats->launches = launches;
+        stats->groups_per_chain = geo.G;
+        stats->waves_per_group = geo.waves;
+        stats->chains_per_pass = 1;
+        stats->lds_resident = geo.resident;
+        stats->bytes_per_pass = ((int64_t)c->n * K + c->n) * (c->f32 ? 4 : 8);
+        stats->passes = (int64_t)n_chains * iters;
+    }
+    for (size_t i = 0; i < C; ++i)
+        if (st[i] != 0)
+            return fail(c, BMC_ETIMEOUT, "persistent Gibbs kernel: bounded spin expired (chain " +
+                                             std::to_string(i) + ")");
+    return BMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmc_abi_version(void) { return PYBMC_AMD_ABI_VERSION; }
+
+int bmc_create(int device_id, bmc_ctx** out) {
+    if (!out) return BMC_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BMC_EHIP;
+    if (device_id < 0 || device_id >= count) return BMC_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return BMC_EHIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BMC_EHIP;  // MI355X only
+    bmc_ctx* c = new (std::nothrow) bmc_ctx();
+    if (!c) return BMC_ENOMEM;
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return BMC_EHIP;
+    }
+    c->own_stream = true;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            bmc_destroy(c);
+            return BMC_EHIP;
+        }
+    *out = c;
+    return BMC_OK;
+}
+
+void bmc_destroy(bmc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->Xraw, &c->Yp, &c->Xrot, &c->dW, &c->dWT, &c->dLam, &c->dC1, &c->dC2,
+                      &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef,
+                      &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
+                      &c->seeds})
+        release(*b);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* bmc_last_error(const bmc_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int bmc_set_stream(bmc_ctx* c, void* hip_stream) {
+    if (!c) return BMC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return BMC_OK;
+}
+
+int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
+    if (!c) return BMC_EINVAL;
+    if (!t) {
+        c->tune = bmc_tuning{0, 0, 0, 0};
+        return BMC_OK;
+    }
+    if (t->groups_per_chain < 0 || t->groups_per_chain > 256 || t->waves_per_group < 0 ||
+        t->waves_per_group > 16)
+        return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..16)");
+    c->tune = *t;
+    return BMC_OK;
+}
+
+int bmc_set_problem(bmc_ctx* c, const void* X, int64_t n, int32_t k, int64_t ldx, int layout,
+                    const void* y, int dtype) {
+    int rc = check_problem_args(c, X, n, k, ldx, layout, y, dtype);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t es = dtype == BMC_F32 ? 4 : 8;
+    const size_t xbytes = (size_t)(layout == BMC_COL_MAJOR ? (size_t)ldx * k : (size_t)ldx * n) * es;
+    const size_t ybytes = (size_t)n * es;
+    const size_t yoff = (xbytes + 255) & ~(size_t)255;
+    if ((rc = ensure(c, c->stage, yoff + ybytes))) return rc;
+    // the last column/row of a strided host matrix may be shorter than ldx
+    const size_t xcopy = layout == BMC_COL_MAJOR ? ((size_t)ldx * (k - 1) + n) * es
+                                                 : ((size_t)ldx * (n - 1) + k) * es;
+    HIPCHK(c, hipMemcpyAsync(c->stage.p, X, xcopy, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char*)c->stage.p + yoff, y, ybytes, hipMemcpyHostToDevice, c->stream));
+    rc = set_problem_common(c, c->stage.p, (char*)c->stage.p + yoff, n, k, ldx, layout, dtype);
+    return rc;
+}
+
+int bmc_set_problem_device(bmc_ctx* c, const void* dX, int64_t n, int32_t k, int64_t ldx,
+                           int layout, const void* dy, int dtype) {
+    int rc = check_problem_args(c, dX, n, k, ldx, layout, dy, dtype);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    return set_problem_common(c, dX, dy, n, k, ldx, layout, dtype);
+}
+
+int bmc_set_prior(bmc_ctx* c, const double* b0, const double* C0, double nu0, double sigma20) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_problem) return fail(c, BMC_ESTATE, "bmc_set_problem must be called first");
+    if (!b0 || !C0) return fail(c, BMC_EINVAL, "b0 and C0 must not be NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_prior = false;
+    const int k = c->k, ka = k + 1;
+    // P = inv(C0)                                          (inference_utils.py:22)
+    bmc_la::Mat P(C0, C0 + (size_t)k * k);
+    if (!bmc_la::invert(P, k)) return fail(c, BMC_ESINGULAR, "Singular matrix (b_mean_cov)");
+    // OLS start value                                      (inference_utils.py:26-37)
+    bmc_la::Mat A((size_t)k * k);
+    std::vector<double> xty(k);
+    for (int i = 0; i < k; ++i) {
+        for (int j = 0; j < k; ++j) A[(size_t)i * k + j] = c->gram[(size_t)i * ka + j];
+        xty[i] = c->gram[(size_t)i * ka + k];
+    }
+    std::vector<double> bols;
+    if (!bmc_la::solve(A, xty, k, bols)) return fail(c, BMC_ESINGULAR, "Singular matrix (X'X)");
+    double rss0 = 0.0;
+    int rc = rss_on_raw(c, bols.data(), 1, &rss0);
+    if (rc) return rc;
+    double s2 = rss0 / (double)c->n;
+    if (!(s2 >= 1e-6)) s2 = s2 != s2 ? s2 : 1e-6;  // max(s2, 1e-6); NaN propagates
+    c->sigma2_init = s2;
+    // basis: B = P + 1e-6 I = L L',  L^-1 A L^-T = Q diag(lam) Q',  W = L^-T Q
+    bmc_la::Mat B((size_t)k * k);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            B[(size_t)i * k + j] = 0.5 * (P[(size_t)i * k + j] + P[(size_t)j * k + i]) +
+                                   (i == j ? 1e-6 : 0.0);
+    bmc_la::Mat L, Li;
+    if (!bmc_la::cholesky(B, k, L))
+        return fail(c, BMC_EINVAL, "prior precision inv(b_mean_cov) + 1e-6 I is not positive definite");
+    bmc_la::lower_inverse(L, k, Li);
+    bmc_la::Mat tmp((size_t)k * k, 0.0), M((size_t)k * k, 0.0);
+    for (int i = 0; i < k; ++i)          // tmp = Li * A
+        for (int m = 0; m <= i; ++m) {
+            const double l = Li[(size_t)i * k + m];
+            if (l == 0.0) continue;
+            for (int j = 0; j < k; ++j) tmp[(size_t)i * k + j] += l * A[(size_t)m * k + j];
+        }
+    for (int i = 0; i < k; ++i)          // M = tmp * Li'
+        for (int j = 0; j < k; ++j) {
+            long double s = 0.0L;
+            for (int m = 0; m <= j; ++m) s += (long double)tmp[(size_t)i * k + m] * Li[(size_t)j * k + m];
+            M[(size_t)i * k + j] = (double)s;
+        }
+    for (int i = 0; i < k; ++i)
+        for (int j = i + 1; j < k; ++j) {
+            const double v = 0.5 * (M[(size_t)i * k + j] + M[(size_t)j * k + i]);
+            M[(size_t)i * k + j] = M[(size_t)j * k + i] = v;
+        }
+    bmc_la::Mat Q;
+    bmc_la::jacobi_eigh(M, k, c->lam, Q);
+    c->W.assign((size_t)k * k, 0.0);
+    for (int i = 0; i < k; ++i)          // W = Li' Q
+        for (int j = 0; j < k; ++j) {
+            long double s = 0.0L;
+            for (int m = i; m < k; ++m) s += (long double)Li[(size_t)m * k + i] * Q[(size_t)m * k + j];
+            c->W[(size_t)i * k + j] = (double)s;
+        }
+    std::vector<double> Pb0(k, 0.0);
+    for (int i = 0; i < k; ++i) {
+        long double s = 0.0L;
+        for (int j = 0; j < k; ++j) s += (long double)P[(size_t)i * k + j] * b0[j];
+        Pb0[i] = (double)s;
+    }
+    c->c1.assign(k, 0.0);
+    c->c2.assign(k, 0.0);
+    for (int j = 0; j < k; ++j) {
+        long double s1 = 0.0L, s2l = 0.0L;
+        for (int i = 0; i < k; ++i) {
+            s1 += (long double)c->W[(size_t)i * k + j] * Pb0[i];
+            s2l += (long double)c->W[(size_t)i * k + j] * xty[i];
+        }
+        c->c1[j] = (double)s1;
+        c->c2[j] = (double)s2l;
+    }
+    c->b0.assign(b0, b0 + k);
+    c->nu0 = nu0;
+    c->s20 = sigma20;
+    std::vector<double> WT((size_t)k * k);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) WT[(size_t)i * k + j] = c->W[(size_t)j * k + i];
+    const size_t kk = (size_t)k * k * 8;
+    if ((rc = ensure(c, c->dW, kk)) || (rc = ensure(c, c->dWT, kk)) ||
+        (rc = ensure(c, c->dLam, (size_t)k * 8)) || (rc = ensure(c, c->dC1, (size_t)k * 8)) ||
+        (rc = ensure(c, c->dC2, (size_t)k * 8)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dW.p, c->W.data(), kk, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dWT.p, WT.data(), kk, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dLam.p, c->lam.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dC1.p, c->c1.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dC2.p, c->c2.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rotate(panels_of(c, c->Xraw.p), (const double*)c->dW.p, c->Xrot.p, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // WT (stack vector) must outlive the copy
+    c->have_prior = true;
+    return BMC_OK;
+}
+
+int bmc_get_gram(bmc_ctx* c, double* out) {
+    if (!c || !out) return BMC_EINVAL;
+    if (!c->have_problem) return fail(c, BMC_ESTATE, "no problem set");
+    std::memcpy(out, c->gram.data(), c->gram.size() * sizeof(double));
+    return BMC_OK;
+}
+
+int bmc_get_basis(bmc_ctx* c, double* W_out, double* lam_out, double* sigma2_init) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_prior) return fail(c, BMC_ESTATE, "no prior set");
+    if (W_out) std::memcpy(W_out, c->W.data(), c->W.size() * sizeof(double));
+    if (lam_out) std::memcpy(lam_out, c->lam.data(), c->lam.size() * sizeof(double));
+    if (sigma2_init) *sigma2_init = c->sigma2_init;
+    return BMC_OK;
+}
+
+int bmc_conditional_moments(bmc_ctx* c, double sigma2, double* mean_out, double* cov_out) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_prior) return fail(c, BMC_ESTATE, "no prior set");
+    const int k = c->k;
+    std::vector<double> d(k), m(k);
+    for (int j = 0; j < k; ++j) {
+        d[j] = 1.0 / (c->lam[j] / sigma2 + 1.0);
+        m[j] = d[j] * (c->c1[j] + c->c2[j] / sigma2);
+    }
+    if (mean_out)
+        for (int i = 0; i < k; ++i) {
+            long double s = 0.0L;
+            for (int j = 0; j < k; ++j) s += (long double)c->W[(size_t)i * k + j] * m[j];
+            mean_out[i] = (double)s;
+        }
+    if (cov_out)
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                long double s = 0.0L;
+                for (int q = 0; q < k; ++q)
+                    s += (long double)c->W[(size_t)i * k + q] * d[q] * c->W[(size_t)j * k + q];
+                cov_out[(size_t)i * k + j] = (double)s;
+            }
+    return BMC_OK;
+}
+
+int bmc_residual_rss(bmc_ctx* c, const double* beta, int32_t nb, double* rss_out) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_problem) return fail(c, BMC_ESTATE, "no problem set");
+    if (!beta || !rss_out || nb < 1) return fail(c, BMC_EINVAL, "beta/rss_out/nb invalid");
+    HIPCHK(c, hipSetDevice(c->device));
+    return rss_on_raw(c, beta, nb, rss_out);
+}
+
+int bmc_residual_rss_bench(bmc_ctx* c, int32_t nb, int32_t reps, double* ms_per_launch) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_problem) return fail(c, BMC_ESTATE, "no problem set");
+    if (nb < 1 || nb > 8 || reps < 1 || !ms_per_launch) return fail(c, BMC_EINVAL, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const Panels P = panels_of(c, c->Xraw.p);
+    int rc;
+    if ((rc = ensure(c, c->rssPartial, (size_t)rss_groups(P) * 8 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->rssOut, 8 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->coef, (size_t)8 * c->k * sizeof(double)))) return rc;
+    std::vector<double> cf((size_t)nb * c->k);
+    for (size_t i = 0; i < cf.size(); ++i) cf[i] = 0.01 * (double)((i * 2654435761u) % 97) - 0.5;
+    HIPCHK(c, hipMemcpyAsync(c->coef.p, cf.data(), cf.size() * 8, hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < 3; ++i)
+        HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p, nb, (double*)c->rssPartial.p,
+                                      (double*)c->rssOut.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    for (int i = 0; i < reps; ++i)
+        HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p, nb, (double*)c->rssPartial.p,
+                                      (double*)c->rssOut.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    *ms_per_launch = (double)ms / reps;
+    return BMC_OK;
+}
+
+int bmc_gibbs_run(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seeds, int rng_mode,
+                  const double* xi, const double* g, double* samples_out, bmc_stats* stats) {
+    if (!c) return BMC_EINVAL;
+    if (!samples_out && iters > 0) return fail(c, BMC_EINVAL, "samples_out must not be NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_common(c, n_chains, iters, seeds, rng_mode, xi, g, samples_out, nullptr, stats);
+}
+
+int bmc_gibbs_run_device(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seeds,
+                         void* d_samples_out, bmc_stats* stats) {
+    if (!c) return BMC_EINVAL;
+    if (!d_samples_out && iters > 0) return fail(c, BMC_EINVAL, "d_samples_out must not be NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_common(c, n_chains, iters, seeds, BMC_RNG_DEVICE, nullptr, nullptr, nullptr,
+                      d_samples_out, stats);
+}
+
+int bmc_rng_fill(bmc_ctx* c, uint64_t seed, int64_t count_normal, double* normals_out, double shape,
+                 int64_t count_gamma, double* gammas_out) {
+    if (!c) return BMC_EINVAL;
+    if (count_normal < 0 || count_gamma < 0 || (count_normal > 0 && !normals_out) ||
+        (count_gamma > 0 && (!gammas_out || !(shape > 0.0))))
+        return fail(c, BMC_EINVAL, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->xi, (size_t)count_normal * 8))) return rc;
+    if ((rc = ensure(c, c->gam, (size_t)count_gamma * 8))) return rc;
+    if ((rc = ensure(c, c->seeds, sizeof(uint64_t)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->seeds.p, &seed, sizeof(seed), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rng_fill((const uint64_t*)c->seeds.p, 1, count_normal, (double*)c->xi.p, shape,
+                              count_gamma, (double*)c->gam.p, c->stream));
+    if (count_normal)
+        HIPCHK(c, hipMemcpyAsync(normals_out, c->xi.p, (size_t)count_normal * 8,
+                                 hipMemcpyDeviceToHost, c->stream));
+    if (count_gamma)
+        HIPCHK(c, hipMemcpyAsync(gammas_out, c->gam.p, (size_t)count_gamma * 8,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMC_OK;
+}
+
+int bmc_philox_raw(bmc_ctx* c, uint64_t seed, uint32_t stream_id, int64_t nblocks4, uint32_t* out) {
+    if (!c) return BMC_EINVAL;
+    if (nblocks4 < 1 || !out) return fail(c, BMC_EINVAL, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->xi, (size_t)nblocks4 * 16))) return rc;
+    HIPCHK(c, launch_philox_raw(seed, stream_id, nblocks4, (uint32_t*)c->xi.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->xi.p, (size_t)nblocks4 * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMC_OK;
+}
+
+}  // extern "C"

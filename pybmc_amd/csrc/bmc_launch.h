@@ -1,0 +1,75 @@
+// Host-callable launchers of the gfx950 kernels (one per kernel family).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmc {
+
+// Storage description of the panelised problem (see bmc_dev.h "panel layout").
+struct Panels {
+    const void* X;   // [NP][K][RP] of T
+    const void* y;   // [NP*RP] of T
+    int64_t n;       // true row count
+    int32_t k;
+    int32_t vec;     // rows per lane (RP = 64*vec)
+    int32_t npanels;
+    int32_t f32;     // 1: T = float, 0: T = double
+};
+
+// ---- set-up ----------------------------------------------------------------
+// user layout (row/col-major, f32/f64, host-uploaded or device) -> panels
+hipError_t launch_panelize(const void* Xsrc, const void* ysrc, int64_t n, int32_t k,
+                           int64_t ldx, int col_major, int f32, int32_t vec,
+                           void* Xp, void* yp, int32_t npanels, hipStream_t s);
+
+// Augmented Gram [X y]'[X y] with v_mfma_f64_16x16x4_f64.  gram_out is
+// (k+1)x(k+1) row-major f64.  scratch: >= gram_scratch_bytes().
+size_t gram_scratch_bytes(const Panels& P);
+hipError_t launch_gram(const Panels& P, void* scratch, double* gram_out, hipStream_t s);
+
+// Xrot = X * W (W k x k row-major, device), same panel layout and storage type.
+hipError_t launch_rotate(const Panels& P, const double* W, void* Xrot, hipStream_t s);
+
+// rss[b] = sum_i (y_i - sum_j X_ij coef[b][j])^2, b < nb (nb <= 8).
+// partial: >= rss_partial_doubles(P) * nb doubles of scratch.
+int32_t rss_groups(const Panels& P);
+hipError_t launch_residual_rss(const Panels& P, const double* coef, int32_t nb,
+                               double* partial, double* rss_out, hipStream_t s);
+
+// samples[c][t][0..k) = W u[c][t][0..k);  samples[c][t][k] = u[c][t][k]
+hipError_t launch_unrotate(const double* uout, const double* W, int32_t k, int64_t rows,
+                           double* samples, hipStream_t s);
+
+// ---- variates ---------------------------------------------------------------
+// normals[c][e], e < per_chain_normals; gammas[c][t], t < per_chain_gammas
+hipError_t launch_rng_fill(const uint64_t* seeds_dev, int32_t n_chains,
+                           int64_t per_chain_normals, double* normals, double shape,
+                           int64_t per_chain_gammas, double* gammas, hipStream_t s);
+hipError_t launch_philox_raw(uint64_t seed, uint32_t stream, int64_t nblocks4,
+                             uint32_t* out, hipStream_t s);
+
+// ---- the persistent Gibbs loop ------------------------------------------------
+struct GibbsArgs {
+    Panels P;               // ROTATED panels
+    const double* lam;      // [k]
+    const double* c1;       // [k]  W' P b0
+    const double* c2;       // [k]  W' X'y
+    double nu0_s20;         // nu0 * sigma20
+    double sigma2_init;
+    const double* xi;       // [C][T][k]
+    const double* gam;      // [C][T]
+    double* uout;           // [C][T][k+1]
+    unsigned long long* gran;  // [C][2][gran_stride] granules, zeroed before launch
+    int32_t gran_stride;    // u64 words per (chain, parity), >= 2*G, multiple of 32
+    int32_t* status;        // [C] 0 ok, 1 timeout
+    int64_t iters;
+    int32_t n_chains;       // chains in THIS launch
+    int32_t G;              // workgroups per chain
+    int32_t waves;          // waves per workgroup
+    int32_t resident;       // panels pinned in LDS
+    int32_t panels_per_group;  // max panels a group owns
+};
+size_t gibbs_lds_bytes(const GibbsArgs& a);
+hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s);
+
+}  // namespace bmc

@@ -1,0 +1,545 @@
+// One-off and auxiliary gfx950 kernels of the Gibbs core:
+//   panelize      user layout -> row panels                       (HBM-bound copy)
+//   gram          [X y]'[X y] with v_mfma_f64_16x16x4_f64          (reference inference_utils.py:25,43)
+//   rotate        Xrot = X W                                       (DESIGN.md "rotated draw")
+//   residual_rss  rss = sum (y - X b)^2, streaming, two-stage sum  (reference inference_utils.py:48-51)
+//   unrotate      beta_t = W u_t                                   (reference inference_utils.py:54)
+//   rng_fill      Philox4x32-10 -> N(0,1) and Gamma(a,1)           (reference inference_utils.py:45,52)
+#include "bmc_dev.h"
+#include "bmc_launch.h"
+
+namespace bmc {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+// =========================================================================
+// panelize
+// =========================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void panelize_kernel(
+    const T* __restrict__ Xs, const T* __restrict__ ys, int64_t n, int32_t k, int64_t ldx,
+    int col_major, int32_t RP, int32_t npanels, T* __restrict__ Xp, T* __restrict__ yp) {
+    const int64_t total = (int64_t)npanels * k * RP;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t p = e / ((int64_t)k * RP);
+        const int64_t rem = e - p * (int64_t)k * RP;
+        const int32_t j = (int32_t)(rem / RP);
+        const int32_t r = (int32_t)(rem - (int64_t)j * RP);
+        const int64_t row = p * RP + r;
+        T v = (T)0;
+        if (row < n) v = col_major ? Xs[row + (int64_t)j * ldx] : Xs[row * ldx + j];
+        Xp[e] = v;
+    }
+    const int64_t ytotal = (int64_t)npanels * RP;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ytotal; e += stride)
+        yp[e] = e < n ? ys[e] : (T)0;
+}
+
+hipError_t launch_panelize(const void* Xsrc, const void* ysrc, int64_t n, int32_t k,
+                           int64_t ldx, int col_major, int f32, int32_t vec, void* Xp,
+                           void* yp, int32_t npanels, hipStream_t s) {
+    const int32_t RP = 64 * vec;
+    const int64_t total = (int64_t)npanels * k * RP;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (f32)
+        hipLaunchKernelGGL(panelize_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const float*)Xsrc, (const float*)ysrc, n, k, ldx, col_major, RP,
+                           npanels, (float*)Xp, (float*)yp);
+    else
+        hipLaunchKernelGGL(panelize_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const double*)Xsrc, (const double*)ysrc, n, k, ldx, col_major, RP,
+                           npanels, (double*)Xp, (double*)yp);
+    return hipGetLastError();
+}
+
+// =========================================================================
+// Gram with f64 MFMA
+// =========================================================================
+// One workgroup (4 waves) owns a chunk of 64-row sub-panels and up to 32 of the
+// upper-triangular 16x16 tile pairs of G = A'A, A = [X | y | 0-pad] (Ka_pad cols).
+// Each sub-panel is staged once into LDS as f64 [Ka_pad][66] (column-major, row
+// stride 66 doubles -> the MFMA operand reads below are bank-conflict free: a
+// 32-lane half covers 16 columns x 2 rows = banks {4c,4c+1} and {4c+2,4c+3}).
+// MFMA operand maps (cdna guide section 3, f64 form): lane l supplies
+// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D: col = l&15,
+// row = (l>>4) + 4*reg.  For G tile (ti,tj): A[i][k] = a[n0+k][16ti+i],
+// B[k][j] = a[n0+k][16tj+j].
+constexpr int GRAM_LDR = 66;
+constexpr int GRAM_TPW = 8;  // tile pairs per wave
+
+template <typename T>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(
+    const T* __restrict__ X, const T* __restrict__ y, int32_t K, int32_t RP, int32_t nsub,
+    int32_t subs_per_chunk, int32_t Ka_pad, int32_t ntile, int32_t npairs,
+    double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.x;
+    const int pair0 = (blockIdx.y * 4 + wave) * GRAM_TPW;
+
+    int ti[GRAM_TPW], tj[GRAM_TPW];
+#pragma unroll
+    for (int q = 0; q < GRAM_TPW; ++q) {
+        // pair id -> (ti, tj), tj >= ti, row-by-row enumeration of the upper triangle
+        int id = pair0 + q, a = 0, rowlen = ntile;
+        if (id >= npairs) id = 0;
+        while (id >= rowlen) { id -= rowlen; ++a; --rowlen; }
+        ti[q] = a;
+        tj[q] = a + id;
+    }
+    f64x4 acc[GRAM_TPW];
+#pragma unroll
+    for (int q = 0; q < GRAM_TPW; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    const int s_begin = chunk * subs_per_chunk;
+    int s_end = s_begin + subs_per_chunk;
+    if (s_end > nsub) s_end = nsub;
+    const int kq = lane >> 4, cl = lane & 15;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int64_t row0 = (int64_t)s * 64;
+        const int64_t p = row0 / RP;
+        const int32_t r0 = (int32_t)(row0 - p * RP);
+        for (int e = tid; e < Ka_pad * 64; e += 256) {
+            const int a = e >> 6, r = e & 63;
+            double v = 0.0;
+            if (a < K) v = (double)X[(p * K + a) * RP + r0 + r];
+            else if (a == K) v = (double)y[row0 + r];
+            tile[a * GRAM_LDR + r] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            const int rr = kk * 4 + kq;
+#pragma unroll
+            for (int q = 0; q < GRAM_TPW; ++q) {
+                if (pair0 + q < npairs) {  // wave-uniform
+                    const double a = tile[(16 * ti[q] + cl) * GRAM_LDR + rr];
+                    const double b = tile[(16 * tj[q] + cl) * GRAM_LDR + rr];
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double* out = partial + (size_t)chunk * Ka_pad * Ka_pad;
+#pragma unroll
+    for (int q = 0; q < GRAM_TPW; ++q) {
+        if (pair0 + q < npairs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * ti[q] + kq + 4 * i;
+                const int col = 16 * tj[q] + cl;
+                out[(size_t)row * Ka_pad + col] = acc[q][i];
+            }
+        }
+    }
+}
+
+// Sum the chunk partials in chunk order (bit-reproducible), mirror to the lower triangle.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial,
+                                                          int32_t nchunk, int32_t Ka,
+                                                          int32_t Ka_pad,
+                                                          double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Ka * Ka) return;
+    const int i = e / Ka, j = e % Ka;
+    if (i > j) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * Ka_pad * Ka_pad + (size_t)i * Ka_pad + j];
+    out[(size_t)i * Ka + j] = s;
+    out[(size_t)j * Ka + i] = s;
+}
+
+static void gram_geometry(const Panels& P, int& Ka_pad, int& ntile, int& npairs, int& nsub,
+                          int& nchunk, int& spc) {
+    Ka_pad = ((P.k + 1 + 15) / 16) * 16;
+    ntile = Ka_pad / 16;
+    npairs = ntile * (ntile + 1) / 2;
+    nsub = P.npanels * P.vec;  // 64-row sub-panels
+    nchunk = nsub < 512 ? nsub : 512;
+    // keep the scratch below ~256 MB for wide problems
+    const size_t per = (size_t)Ka_pad * Ka_pad * 8;
+    while (nchunk > 1 && per * nchunk > ((size_t)256 << 20)) nchunk = (nchunk + 1) / 2;
+    spc = (nsub + nchunk - 1) / nchunk;
+    nchunk = (nsub + spc - 1) / spc;
+}
+
+size_t gram_scratch_bytes(const Panels& P) {
+    int Ka_pad, ntile, npairs, nsub, nchunk, spc;
+    gram_geometry(P, Ka_pad, ntile, npairs, nsub, nchunk, spc);
+    return (size_t)nchunk * Ka_pad * Ka_pad * sizeof(double);
+}
+
+hipError_t launch_gram(const Panels& P, void* scratch, double* gram_out, hipStream_t s) {
+    int Ka_pad, ntile, npairs, nsub, nchunk, spc;
+    gram_geometry(P, Ka_pad, ntile, npairs, nsub, nchunk, spc);
+    const int pgroups = (npairs + 4 * GRAM_TPW - 1) / (4 * GRAM_TPW);
+    const size_t lds = (size_t)Ka_pad * GRAM_LDR * sizeof(double);
+    const int RP = 64 * P.vec;
+    hipError_t e;
+    if (P.f32) {
+        e = hipFuncSetAttribute((const void*)gram_mfma_kernel<float>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gram_mfma_kernel<float>, dim3(nchunk, pgroups), dim3(256), lds, s,
+                           (const float*)P.X, (const float*)P.y, P.k, RP, nsub, spc, Ka_pad,
+                           ntile, npairs, (double*)scratch);
+    } else {
+        e = hipFuncSetAttribute((const void*)gram_mfma_kernel<double>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gram_mfma_kernel<double>, dim3(nchunk, pgroups), dim3(256), lds, s,
+                           (const double*)P.X, (const double*)P.y, P.k, RP, nsub, spc, Ka_pad,
+                           ntile, npairs, (double*)scratch);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int Ka = P.k + 1;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((Ka * Ka + 255) / 256), dim3(256), 0, s,
+                       (const double*)scratch, nchunk, Ka, Ka_pad, gram_out);
+    return hipGetLastError();
+}
+
+// =========================================================================
+// rotate: Xrot = X W
+// =========================================================================
+// One wave produces JT = 8 output columns of one panel: it streams the panel's K
+// input columns once (coalesced, VEC rows per lane) and keeps 8*VEC accumulators.
+constexpr int ROT_JT = 8;
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void rotate_kernel(const T* __restrict__ X,
+                                                     const double* __restrict__ W, int32_t K,
+                                                     T* __restrict__ Xrot) {
+    constexpr int RP = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = (blockIdx.y * 4 + wave) * ROT_JT;
+    if (j0 >= K) return;
+    const int64_t p = blockIdx.x;
+    const T* xp = X + p * (int64_t)K * RP + lane * VEC;
+    double acc[ROT_JT][VEC];
+#pragma unroll
+    for (int q = 0; q < ROT_JT; ++q)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[q][v] = 0.0;
+    for (int i = 0; i < K; ++i) {
+        double x[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[v] = (double)xp[(int64_t)i * RP + v];
+#pragma unroll
+        for (int q = 0; q < ROT_JT; ++q) {
+            const double w = (j0 + q < K) ? W[(size_t)i * K + j0 + q] : 0.0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[q][v] = fma(x[v], w, acc[q][v]);
+        }
+    }
+    T* op = Xrot + p * (int64_t)K * RP + lane * VEC;
+#pragma unroll
+    for (int q = 0; q < ROT_JT; ++q)
+        if (j0 + q < K)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) op[(int64_t)(j0 + q) * RP + v] = (T)acc[q][v];
+}
+
+template <typename T>
+static hipError_t rotate_dispatch(const Panels& P, const double* W, void* Xrot, hipStream_t s) {
+    dim3 grid(P.npanels, (P.k + 4 * ROT_JT - 1) / (4 * ROT_JT));
+#define BMC_ROT(V)                                                                       \
+    hipLaunchKernelGGL((rotate_kernel<T, V>), grid, dim3(256), 0, s, (const T*)P.X, W, P.k, \
+                       (T*)Xrot)
+    switch (P.vec) {
+        case 1: BMC_ROT(1); break;
+        case 2: BMC_ROT(2); break;
+        case 4: BMC_ROT(4); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef BMC_ROT
+    return hipGetLastError();
+}
+
+hipError_t launch_rotate(const Panels& P, const double* W, void* Xrot, hipStream_t s) {
+    return P.f32 ? rotate_dispatch<float>(P, W, Xrot, s) : rotate_dispatch<double>(P, W, Xrot, s);
+}
+
+// =========================================================================
+// residual_rss (stand-alone streaming form)
+// =========================================================================
+// Wave-slot w walks panels w, w+S, ...; lane holds VEC rows; per column one
+// coalesced 64*VEC*sizeof(T)-byte read of X shared by NB coefficient vectors.
+// Stage 1 leaves one partial per workgroup; stage 2 sums them in index order.
+template <typename T, int VEC, int NB>
+__global__ __launch_bounds__(256) void residual_rss_kernel(
+    const T* __restrict__ X, const T* __restrict__ y, int32_t K, int32_t npanels,
+    const double* __restrict__ coef, int32_t nb, double* __restrict__ partial) {
+    constexpr int RP = 64 * VEC;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* cf = reinterpret_cast<double*>(smem_raw);         // [K][NB]
+    double* red = cf + (size_t)K * NB;                         // [4][NB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < K * NB; e += 256) {
+        const int j = e / NB, b = e % NB;
+        cf[e] = b < nb ? coef[(size_t)b * K + j] : 0.0;
+    }
+    __syncthreads();
+    double s[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = 0.0;
+    const int slots = gridDim.x * 4;
+    for (int p = blockIdx.x * 4 + wave; p < npanels; p += slots) {
+        const T* xp = X + (int64_t)p * K * RP + lane * VEC;
+        double acc[NB][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const double yv = (double)y[(int64_t)p * RP + lane * VEC + v];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b][v] = yv;
+        }
+#pragma unroll 8
+        for (int j = 0; j < K; ++j) {
+            T xv[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xv[v] = xp[(int64_t)j * RP + v];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double c = cf[j * NB + b];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[b][v] = fma(-(double)xv[v], c, acc[b][v]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[b] = fma(acc[b][v], acc[b][v], s[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const double t = wave_sum(s[b]);
+        if (lane == 0) red[wave * NB + b] = t;
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const double t = ((red[tid] + red[NB + tid]) + red[2 * NB + tid]) + red[3 * NB + tid];
+        partial[(size_t)blockIdx.x * NB + tid] = t;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void rss_final_kernel(const double* __restrict__ partial,
+                                                       int32_t ngroups, int32_t nb,
+                                                       double* __restrict__ rss) {
+    const int lane = threadIdx.x;
+    for (int b = 0; b < nb; ++b) {
+        double s = 0.0;
+        for (int g = lane; g < ngroups; g += 64) s += partial[(size_t)g * NB + b];
+        s = wave_sum(s);
+        if (lane == 0) rss[b] = s;
+    }
+}
+
+int32_t rss_groups(const Panels& P) {
+    int32_t g = (P.npanels + 3) / 4;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return g;
+}
+
+template <typename T, int VEC>
+static hipError_t rss_dispatch(const Panels& P, const double* coef, int32_t nb, double* partial,
+                               double* rss_out, hipStream_t s) {
+    const int32_t G = rss_groups(P);
+#define BMC_RSS(NBV)                                                                         \
+    do {                                                                                     \
+        const size_t lds = ((size_t)P.k * NBV + 4 * NBV) * sizeof(double);                   \
+        hipError_t e = hipFuncSetAttribute((const void*)residual_rss_kernel<T, VEC, NBV>,    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                           (int)lds);                                        \
+        if (e != hipSuccess) return e;                                                       \
+        hipLaunchKernelGGL((residual_rss_kernel<T, VEC, NBV>), dim3(G), dim3(256), lds, s,   \
+                           (const T*)P.X, (const T*)P.y, P.k, P.npanels, coef, nb, partial); \
+        hipLaunchKernelGGL((rss_final_kernel<NBV>), dim3(1), dim3(64), 0, s,                 \
+                           (const double*)partial, G, nb, rss_out);                          \
+    } while (0)
+    if (nb <= 1) BMC_RSS(1);
+    else if (nb <= 2) BMC_RSS(2);
+    else if (nb <= 4) BMC_RSS(4);
+    else if (nb <= 8) BMC_RSS(8);
+    else return hipErrorInvalidValue;
+#undef BMC_RSS
+    return hipGetLastError();
+}
+
+hipError_t launch_residual_rss(const Panels& P, const double* coef, int32_t nb, double* partial,
+                               double* rss_out, hipStream_t s) {
+    if (P.f32) {
+        switch (P.vec) {
+            case 1: return rss_dispatch<float, 1>(P, coef, nb, partial, rss_out, s);
+            case 2: return rss_dispatch<float, 2>(P, coef, nb, partial, rss_out, s);
+            case 4: return rss_dispatch<float, 4>(P, coef, nb, partial, rss_out, s);
+        }
+    } else {
+        switch (P.vec) {
+            case 1: return rss_dispatch<double, 1>(P, coef, nb, partial, rss_out, s);
+            case 2: return rss_dispatch<double, 2>(P, coef, nb, partial, rss_out, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+// =========================================================================
+// unrotate: beta_t = W u_t
+// =========================================================================
+// WT is W transposed (WT[i*K + j] = W[j][i]) so that consecutive threads (j)
+// read consecutive words.  Fixed i order -> bit-reproducible.
+__global__ __launch_bounds__(256) void unrotate_kernel(const double* __restrict__ u,
+                                                       const double* __restrict__ WT,
+                                                       int32_t K, int64_t rows,
+                                                       double* __restrict__ out) {
+    const int64_t total = rows * (K + 1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / (K + 1);
+        const int32_t j = (int32_t)(e - r * (K + 1));
+        const double* ur = u + r * (K + 1);
+        double v;
+        if (j == K) {
+            v = ur[K];
+        } else {
+            v = 0.0;
+            for (int i = 0; i < K; ++i) v = fma(WT[(size_t)i * K + j], ur[i], v);
+        }
+        out[e] = v;
+    }
+}
+
+hipError_t launch_unrotate(const double* uout, const double* WT, int32_t k, int64_t rows,
+                           double* samples, hipStream_t s) {
+    const int64_t total = rows * (k + 1);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(unrotate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, uout, WT, k,
+                       rows, samples);
+    return hipGetLastError();
+}
+
+// =========================================================================
+// variates
+// =========================================================================
+// Element e of a chain's normal stream is half of Box-Muller pair e/2, generated
+// from Philox counter (pair_lo, pair_hi, STREAM_NORMAL, 0) under the chain's key,
+// so a chain's variates depend on (seed, e) only -- not on the launch geometry,
+// the chain's index or the number of GPUs.
+__device__ __forceinline__ void box_muller(u32x4 r, double& z0, double& z1) {
+    const double u1 = u53_open0(r.x, r.y), u2 = u53_open0(r.z, r.w);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
+}
+
+__global__ __launch_bounds__(256) void normal_fill_kernel(const uint64_t* __restrict__ seeds,
+                                                          int64_t per_chain,
+                                                          double* __restrict__ out) {
+    const int c = blockIdx.y;
+    const uint64_t seed = seeds[c];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t npairs = (per_chain + 1) / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double* o = out + (int64_t)c * per_chain;
+    for (int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pr < npairs; pr += stride) {
+        const u32x4 r = philox4x32_10(u32x4{(uint32_t)pr, (uint32_t)((uint64_t)pr >> 32),
+                                            STREAM_NORMAL, 0u}, k0, k1);
+        double z0, z1;
+        box_muller(r, z0, z1);
+        o[2 * pr] = z0;
+        if (2 * pr + 1 < per_chain) o[2 * pr + 1] = z1;
+    }
+}
+
+// Gamma(a, 1), Marsaglia & Tsang (2000).  Attempt m of element t uses Philox
+// counters (t_lo, t_hi, STREAM_GAMMA, 2m) and (.., 2m+1).  For a < 1 the usual
+// boost Gamma(a) = Gamma(a+1) * U^(1/a) is applied.
+__device__ inline double gamma_mt(double a, uint64_t t, uint32_t k0, uint32_t k1) {
+    const bool boost = a < 1.0;
+    const double aa = boost ? a + 1.0 : a;
+    const double d = aa - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    double res = d;
+    for (uint32_t m = 0; m < 64; ++m) {
+        const u32x4 r0 = philox4x32_10(u32x4{(uint32_t)t, (uint32_t)(t >> 32), STREAM_GAMMA, 2 * m},
+                                       k0, k1);
+        const u32x4 r1 = philox4x32_10(
+            u32x4{(uint32_t)t, (uint32_t)(t >> 32), STREAM_GAMMA, 2 * m + 1}, k0, k1);
+        double x, unused;
+        box_muller(r0, x, unused);
+        const double u = u53_open0(r1.x, r1.y);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        const double x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2 || log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) {
+            res = d * v;
+            if (boost) res *= pow(u53_open0(r1.z, r1.w), 1.0 / a);
+            break;
+        }
+    }
+    return res;
+}
+
+__global__ __launch_bounds__(256) void gamma_fill_kernel(const uint64_t* __restrict__ seeds,
+                                                         double shape, int64_t per_chain,
+                                                         double* __restrict__ out) {
+    const int c = blockIdx.y;
+    const uint64_t seed = seeds[c];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < per_chain; t += stride)
+        out[(int64_t)c * per_chain + t] = gamma_mt(shape, (uint64_t)t, k0, k1);
+}
+
+hipError_t launch_rng_fill(const uint64_t* seeds_dev, int32_t n_chains, int64_t per_chain_normals,
+                           double* normals, double shape, int64_t per_chain_gammas,
+                           double* gammas, hipStream_t s) {
+    if (per_chain_normals > 0) {
+        int64_t blocks = ((per_chain_normals + 1) / 2 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)blocks, n_chains), dim3(256), 0, s,
+                           seeds_dev, per_chain_normals, normals);
+    }
+    if (per_chain_gammas > 0) {
+        int64_t blocks = (per_chain_gammas + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gamma_fill_kernel, dim3((unsigned)blocks, n_chains), dim3(256), 0, s,
+                           seeds_dev, shape, per_chain_gammas, gammas);
+    }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void philox_raw_kernel(uint32_t k0, uint32_t k1,
+                                                         uint32_t stream, int64_t n4,
+                                                         uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const u32x4 r = philox4x32_10(u32x4{(uint32_t)i, (uint32_t)((uint64_t)i >> 32), stream, 0u},
+                                  k0, k1);
+    out[4 * i + 0] = r.x;
+    out[4 * i + 1] = r.y;
+    out[4 * i + 2] = r.z;
+    out[4 * i + 3] = r.w;
+}
+
+hipError_t launch_philox_raw(uint64_t seed, uint32_t stream, int64_t nblocks4, uint32_t* out,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(philox_raw_kernel, dim3((unsigned)((nblocks4 + 255) / 256)), dim3(256), 0,
+                       s, (uint32_t)seed, (uint32_t)(seed >> 32), stream, nblocks4, out);
+    return hipGetLastError();
+}
+
+}  // namespace bmc

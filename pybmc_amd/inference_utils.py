@@ -1,0 +1,61 @@
+"""Host-side mirror of the reference's ``pybmc/inference_utils.py`` surface.
+
+``gibbs_sampler`` keeps the reference signature and return layout
+(reference inference_utils.py:4-56) and runs on the MI355X through the C ABI.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def _draw_seeds(n):
+    """Seeds come from numpy's legacy global stream -- the stream the reference's
+    beta draw consumes (inference_utils.py:45) -- so ``np.random.seed(s)`` before a
+    call makes a run repeatable (the reference itself is not: its sigma2 draw uses
+    an unseeded generator, inference_utils.py:52)."""
+    hi = np.random.randint(0, 2 ** 32, size=n, dtype=np.uint64)
+    lo = np.random.randint(0, 2 ** 32, size=n, dtype=np.uint64)
+    return (hi << np.uint64(32)) | lo
+
+
+def gibbs_sampler(y, X, iterations, prior_info, *, n_chains=1, seeds=None, device=0,
+                  dtype=None, return_stats=False):
+    """Gibbs sampling for Bayesian linear regression on the GPU.
+
+    Same arguments and result as the reference (inference_utils.py:4-20):
+    ``prior_info = (b_mean_prior, b_mean_cov, nu0, sigma20)``; returns an
+    ``(iterations, k+1)`` array whose rows are ``[beta, sigma]`` (the last column is
+    sigma, not sigma**2, :54).  Raises ``numpy.linalg.LinAlgError`` where the
+    reference's ``inv`` calls do (:22, :26).
+
+    Extensions (keyword-only, defaults preserve the reference behaviour):
+    ``n_chains`` > 1 returns ``(n_chains, iterations, k+1)``; ``seeds`` fixes the
+    per-chain Philox keys; ``dtype=np.float32`` stores X and y in float32 (sums
+    stay float64).
+    """
+    b0, C0, nu0, s20 = prior_info
+    ctx = _lib.default_context(device)
+    ctx.set_problem(y, X, dtype=dtype)
+    ctx.set_prior(b0, C0, nu0, s20)
+    if seeds is None:
+        seeds = _draw_seeds(n_chains)
+    out, stats = ctx.gibbs_run(n_chains, int(iterations), seeds=seeds)
+    res = out[0] if n_chains == 1 else out
+    return (res, stats) if return_stats else res
+
+
+def USVt_hat_extraction(U, S, Vt, components_kept):
+    """Truncate an SVD to ``components_kept`` components
+    (reference inference_utils.py:147-168).  ``U_hat`` is returned column-major
+    (F-contiguous), which is also the layout the device kernels read natively."""
+    k = int(components_kept)
+    U = np.asarray(U)
+    S = np.asarray(S)
+    Vt = np.asarray(Vt)
+    U_hat = np.asfortranarray(U[:, :k])
+    S_hat = S[:k]
+    Vt_hat_normalized = np.array(Vt[:k])
+    Vt_hat = Vt_hat_normalized / S_hat[:, None]
+    return U_hat, S_hat, Vt_hat, Vt_hat_normalized
