@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the Gibbs hot path: Gibbs samples/s (all chains) at N_obs=10000, K=32.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete pass of the hot path over the synthetic workload: every
+chain of this rank runs ``--iters`` (default 50000) Gibbs iterations -- on-device
+variate generation, the persistent loop kernel, the un-rotation of the draws --
+and, for N > 1, the one RCCL all-gather that pools the chains.  X, y and the prior
+are resident in HBM before the timed region starts.  Weak scaling: one chain per
+GPU by default (BASELINE.json configs[1] at N=1, configs[2] at N=8).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(problem, budget_s=12.0, chunk=1000):
+    """Time the numpy port of the reference loop (oracle/bmc_oracle.gibbs_port: same
+    numpy calls per iteration as reference inference_utils.py:39-54) on the host for
+    about ``budget_s`` seconds of the same C2 workload."""
+    from oracle import bmc_oracle as O
+    y, X, prior = problem["y"], problem["X"], problem["prior"]
+    O.gibbs_port(y, X, 20, prior)  # warm BLAS
+    done, t0 = 0, time.perf_counter()
+    while True:
+        O.gibbs_port(y, X, chunk, prior)
+        done += chunk
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if info:
+            threads = int(info[0]["num_threads"])
+    except Exception:
+        pass
+    return {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{done} iterations of 1 chain (N=10000, K=32, f64), numpy port of "
+                      f"reference gibbs_sampler, {el:.1f} s, BLAS threads={threads} of "
+                      f"{os.cpu_count()} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=50000)
+    ap.add_argument("--chains-per-gpu", type=int, default=1)
+    ap.add_argument("--n-obs", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--groups", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch  # first: the HIP runtime torch ships must be the one in the process
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pybmc_amd import _lib
+    from pybmc_amd.chains import chain_block, chain_seeds, pool_samples
+    from pybmc_amd.synthetic import synth_problem
+
+    N, K, T, cpg = args.n_obs, args.k, args.iters, args.chains_per_gpu
+    prob = synth_problem(N, K + 1, K, seed=0)
+    ctx = _lib.Context(local_rank)
+    ctx.set_problem(prob["y"], prob["X"])              # X, y -> HBM (outside the timed region)
+    ctx.set_prior(*prob["prior"])
+    if args.groups or args.waves:
+        ctx.set_tuning(args.groups, args.waves)
+    n_chains = world * cpg
+    mine = chain_block(n_chains, world, rank)
+    seeds = chain_seeds(1, mine)
+    out = torch.empty((len(mine), T, K + 1), dtype=torch.float64, device=dev)
+
+    loop_ms, bytes_moved = [], []
+
+    def step(record):
+        st = ctx.gibbs_run_device(len(mine), T, seeds, out.data_ptr())
+        pooled = pool_samples(out, n_chains) if world > 1 else out
+        if record:
+            loop_ms.append(st["loop_ms"])
+            bytes_moved.append(st["passes"] * st["bytes_per_pass"] / max(st["chains_per_pass"], 1))
+        return st, pooled
+
+    for _ in range(args.warmup):
+        st, pooled = step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, pooled = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity on the last pooled block: finite and centred on the generating coefficients
+    host = pooled[:, T // 5:, :].mean(dim=(0, 1)).cpu().numpy()
+    assert np.isfinite(host).all()
+    assert abs(host[-1] - 0.1) < 0.01, f"posterior sigma {host[-1]} is off the generating 0.1"
+
+    if rank == 0:
+        total_samples = n_chains * T * args.steps
+        value = total_samples / elapsed
+        avg_loop_ms = float(np.mean(loop_ms))
+        achieved = float(np.mean(bytes_moved)) / (avg_loop_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Gibbs samples/sec (all chains) at N_obs=10k, K=32",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C2: synthetic N_obs={N}, K={K}, f64, {cpg} chain/GPU x {T} "
+                                   f"iterations per step, 1 RCCL all-gather per step when N>1",
+                       "n_obs": N, "k": K, "iters_per_step": T, "chains_per_gpu": cpg,
+                       "parallelism": f"chain-per-gpu x{world}",
+                       "groups_per_chain": st["groups_per_chain"],
+                       "waves_per_group": st["waves_per_group"],
+                       "lds_resident": bool(st["lds_resident"])},
+            "roofline": {"bound": "hbm", "kernel": "gibbs_loop_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "note": "algorithmic bytes (N*K+N)*8 per iteration x iterations / "
+                                 "HIP-event time of the loop kernel; at this size the panels are "
+                                 "LDS-resident so HBM traffic is ~0 (see DESIGN.md)",
+                         "loop_ms_per_launch": avg_loop_ms,
+                         "us_per_iteration": avg_loop_ms * 1e3 / T},
+        }
+        if world == 1 and not args.no_extra:
+            extra = {}
+            try:
+                seeds8 = chain_seeds(1, list(range(8)))
+                out8 = torch.empty((8, T, K + 1), dtype=torch.float64, device=dev)
+                ctx.gibbs_run_device(8, T, seeds8, out8.data_ptr())
+                t1 = time.perf_counter()
+                st8 = ctx.gibbs_run_device(8, T, seeds8, out8.data_ptr())
+                torch.cuda.synchronize()
+                e8 = time.perf_counter() - t1
+                extra["chains8_one_gpu"] = {"samples_per_s": 8 * T / e8, "loop_ms": st8["loop_ms"],
+                                            "groups_per_chain": st8["groups_per_chain"]}
+                del out8
+            except Exception as e:  # never lose the headline line
+                extra["chains8_one_gpu"] = {"error": str(e)}
+            try:
+                # residual-reduction kernel at the C4 size (N=200000, K=64, f32 storage)
+                rng = np.random.Generator(np.random.PCG64(4))
+                X4 = np.asfortranarray(rng.standard_normal((200000, 64), dtype=np.float32))
+                y4 = rng.standard_normal(200000, dtype=np.float32)
+                c4 = _lib.Context(local_rank)
+                c4.set_problem(y4, X4, dtype=np.float32)
+                ms = c4.residual_rss_bench(nb=1, reps=50)
+                b4 = (200000 * 64 + 200000) * 4
+                extra["residual_rss_c4"] = {"ms_per_pass": ms, "achieved_GBs": b4 / (ms * 1e-3) / 1e9,
+                                            "frac_of_8TBs": b4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "bytes_per_pass": b4}
+                c4.close()
+            except Exception as e:
+                extra["residual_rss_c4"] = {"error": str(e)}
+            line["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(prob)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

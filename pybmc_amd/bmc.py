@@ -1,0 +1,193 @@
+"""``BayesianModelCombination`` with the reference's method surface
+(reference pybmc/bmc.py:11-376), backed by the MI355X Gibbs core.
+
+Host-side pandas/numpy bookkeeping is restated here; the sampling
+(``train`` -> ``gibbs_sampler``) and the posterior predictive
+(``predict*``/``evaluate`` -> ``rndm_m_random_calculator``) run on the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+from .inference_utils import USVt_hat_extraction, gibbs_sampler, gibbs_sampler_simplex
+from .sampling_utils import coverage, rndm_m_random_calculator
+
+
+class BayesianModelCombination:
+    """Bayesian model combination of several models' predictions.
+
+    Constructor arguments, attributes and methods follow reference bmc.py:46-77.
+    Unlike the reference, ``samples`` and the SVD attributes start as ``None`` so the
+    "call orthogonalize()/train() first" guards raise the intended ``ValueError``
+    (the reference raises ``AttributeError`` there).
+    """
+
+    def __init__(self, models_list, data_dict, truth_column_name, weights=None, device=0):
+        if not isinstance(models_list, list) or any(not isinstance(m, str) for m in models_list):
+            raise ValueError(
+                "The 'models' should be a list of model names (strings) for Bayesian Combination.")
+        if not isinstance(data_dict, dict) or any(
+                not isinstance(df, pd.DataFrame) for df in data_dict.values()):
+            raise ValueError(
+                "The 'data_dict' should be a dictionary of pandas DataFrames, one per property.")
+        self.data_dict = data_dict
+        self.models_list = models_list
+        # only the literal "truth" is dropped (reference bmc.py:75, quirk Q9)
+        self.models = [m for m in models_list if m != "truth"]
+        self.weights = weights
+        self.truth_column_name = truth_column_name
+        self.device = device
+        self.samples = None
+        self.current_property = None
+        self.centered_experiment_train = None
+        self.U_hat = self.S_hat = self.Vt_hat = self.Vt_hat_normalized = None
+        self._predictions_mean_train = None
+        self.last_stats = None
+
+    # ------------------------------------------------------------------ set-up
+    def orthogonalize(self, property, train_df, components_kept):
+        """Centre the model predictions and keep ``components_kept`` SVD components
+        (reference bmc.py:79-130).  A thin SVD is used: its leading columns equal the
+        reference's full-matrices ones and it does not need O(N^2) memory."""
+        self.current_property = property
+        self.selected_models_dataset = self.data_dict[property].copy()
+        F = train_df[self.models].values
+        k = int(components_kept)
+        if k < 1 or k > min(F.shape):
+            raise ValueError("components_kept must be between 1 and min(n_rows, n_models)")
+        mu = np.mean(F, axis=1)
+        y_c = train_df[self.truth_column_name].values - mu
+        Fc = F - mu[:, None]
+        U, S, Vt = np.linalg.svd(Fc, full_matrices=False)
+        if S[k - 1] <= S[0] * 1e-13 * max(F.shape):
+            raise ValueError(
+                "components_kept reaches the null space of the centred model matrix "
+                "(rows sum to zero, so at most n_models - 1 components carry signal)")
+        U_hat, S_hat, Vt_hat, Vt_norm = USVt_hat_extraction(U, S, Vt, k)
+        self.centered_experiment_train = y_c
+        self.U_hat, self.S_hat = U_hat, S_hat
+        self.Vt_hat, self.Vt_hat_normalized = Vt_hat, Vt_norm
+        self._predictions_mean_train = mu
+
+    # ------------------------------------------------------------------- train
+    def train(self, training_options=None):
+        """Sample the posterior (reference bmc.py:132-193).  Options and their defaults
+        are the reference's; any sampler string other than ``"simplex"`` selects the
+        Gibbs sampler (quirk Q6).  Extra optional keys: ``n_chains``, ``seeds``."""
+        if self.U_hat is None:
+            raise ValueError("Must call `orthogonalize()` before training.")
+        opts = training_options if training_options is not None else {}
+
+        def get_option(key, default):
+            if key not in opts:
+                print(f"[INFO] Using default value for '{key}': {default}")
+            return opts.get(key, default)
+
+        iterations = get_option("iterations", 50000)
+        sampler = get_option("sampler", "gibbs_sampling")
+        burn = get_option("burn", 10000)
+        stepsize = get_option("stepsize", 0.001)
+        kc = self.U_hat.shape[1]
+        b_mean_prior = get_option("b_mean_prior", np.zeros(kc))
+        b_mean_cov = get_option("b_mean_cov", np.diag(self.S_hat ** 2))
+        nu0 = get_option("nu0_chosen", 1.0)
+        sigma20 = get_option("sigma20_chosen", 0.02)
+
+        if sampler == "simplex":
+            self.samples = gibbs_sampler_simplex(
+                self.centered_experiment_train, self.U_hat, self.Vt_hat, self.S_hat,
+                iterations, [nu0, sigma20], burn=burn, stepsize=stepsize, device=self.device)
+        else:
+            res, stats = gibbs_sampler(
+                self.centered_experiment_train, self.U_hat, iterations,
+                [b_mean_prior, b_mean_cov, nu0, sigma20],
+                n_chains=int(opts.get("n_chains", 1)), seeds=opts.get("seeds"),
+                device=self.device, return_stats=True)
+            self.last_stats = stats
+            # several chains are pooled along the sample axis
+            self.samples = res if res.ndim == 2 else res.reshape(-1, res.shape[-1])
+
+    # ----------------------------------------------------------------- predict
+    def _require_trained(self):
+        if self.samples is None or self.Vt_hat is None:
+            raise ValueError("Must call `orthogonalize()` and `train()` before predicting.")
+
+    @staticmethod
+    def _band_frames(domain_df, lower, median, upper):
+        frames = []
+        for name, vals in (("Predicted_Lower", lower), ("Predicted_Median", median),
+                           ("Predicted_Upper", upper)):
+            f = domain_df.copy()
+            f[name] = vals
+            frames.append(f)
+        return frames
+
+    def predict(self, X):
+        """Posterior predictive for a DataFrame of model predictions
+        (reference bmc.py:195-242)."""
+        self._require_trained()
+        if not isinstance(X, pd.DataFrame):
+            raise ValueError(
+                "X must be a pandas DataFrame containing model predictions and domain info.")
+        domain_keys = [c for c in X.columns if c not in self.models]
+        rndm_m, (lo, med, up) = rndm_m_random_calculator(
+            X[self.models].values, self.samples, self.Vt_hat, device=self.device)
+        lo_df, med_df, up_df = self._band_frames(X[domain_keys].reset_index(drop=True),
+                                                 lo, med, up)
+        return rndm_m, lo_df, med_df, up_df
+
+    def predict2(self, property):
+        """Posterior predictive for a property of ``data_dict``
+        (reference bmc.py:244-337), including its model-set checks and prints."""
+        self._require_trained()
+        if property not in self.data_dict:
+            raise KeyError(f"Property '{property}' not found in data_dict.")
+        df = self.data_dict[property].copy()
+        domain_keys = [c for c in df.columns
+                       if c not in self.models and c != self.truth_column_name]
+        available = [c for c in df.columns if c in self.models]
+        trained_set, available_set = set(self.models), set(available)
+        print(f"Available models: {available_set}")
+        print(f"Trained models: {trained_set}")
+        extra = available_set - trained_set
+        if extra:
+            raise ValueError(
+                f"ERROR: Property '{property}' contains extra models not present during "
+                f"training: {list(extra)}. You must retrain if using a larger model space.")
+        missing = trained_set - available_set
+        if missing:
+            print(f"WARNING: Predicting on property '{property}' with missing models: "
+                  f"{list(missing)}")
+            print("         The trained model weights include these models — prediction will "
+                  "proceed, but results may not be statistically accurate.")
+        if not available:
+            raise ValueError("No available trained models are present in prediction DataFrame.")
+        idx = [self.models.index(m) for m in available]
+        rndm_m, (lo, med, up) = rndm_m_random_calculator(
+            df[available].values, self.samples, self.Vt_hat[:, idx], device=self.device)
+        lo_df, med_df, up_df = self._band_frames(df[domain_keys].reset_index(drop=True),
+                                                 lo, med, up)
+        return rndm_m, lo_df, med_df, up_df
+
+    # ---------------------------------------------------------------- evaluate
+    def evaluate(self, domain_filter=None):
+        """Coverage of the credible intervals at 0,5,...,100 %
+        (reference bmc.py:339-376; same filter semantics)."""
+        self._require_trained()
+        df = self.data_dict[self.current_property]
+        if domain_filter:
+            for col, cond in domain_filter.items():
+                if col == "multi" and callable(cond):
+                    df = df[df.apply(cond, axis=1)]
+                elif callable(cond):
+                    df = df[cond(df[col])]
+                elif isinstance(cond, tuple) and len(cond) == 2:
+                    df = df[df[col].between(*cond)]
+                elif isinstance(cond, list):
+                    df = df[df[col].isin(cond)]
+                else:
+                    df = df[df[col] == cond]
+        rndm_m, _ = rndm_m_random_calculator(df[self.models].to_numpy(), self.samples,
+                                             self.Vt_hat, device=self.device)
+        return coverage(np.arange(0, 101, 5), rndm_m, df, truth_column=self.truth_column_name)

@@ -59,3 +59,23 @@ def USVt_hat_extraction(U, S, Vt, components_kept):
     Vt_hat_normalized = np.array(Vt[:k])
     Vt_hat = Vt_hat_normalized / S_hat[:, None]
     return U_hat, S_hat, Vt_hat, Vt_hat_normalized
+
+
+def gibbs_sampler_simplex(y, X, Vt_hat, S_hat, iterations, prior_info, burn=10000,
+                          stepsize=0.001, *, seed=None, device=0):
+    """Random-walk Metropolis on the weight simplex with a Gibbs sigma2 step
+    (reference inference_utils.py:59-144).  Same arguments, result, ``ValueError``s
+    (:91-94) and acceptance-rate print (:143) as the reference."""
+    if burn < 0:
+        raise ValueError("Burn-in iterations must be non-negative.")
+    if stepsize <= 0:
+        raise ValueError("Stepsize must be positive.")
+    nu0, s20 = prior_info
+    ctx = _lib.default_context(device)
+    ctx.set_problem(y, X)
+    if seed is None:
+        seed = int(_draw_seeds(1)[0])
+    samples, accepted = ctx.simplex_run(Vt_hat, S_hat, int(iterations), float(nu0), float(s20),
+                                        int(burn), float(stepsize), seed=seed)
+    print(f"Acceptance rate: {accepted / iterations * 100:.2f}%")
+    return samples

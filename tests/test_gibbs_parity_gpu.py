@@ -1,0 +1,304 @@
+"""Parity of the HIP Gibbs path with the reference, through the C ABI  (-m gpu).
+
+Tiers:
+  T1 step-wise      Gram, OLS sigma2_0, mean/cov of beta | sigma2, rss        1e-12 rel
+  T2 whole chain    the reference's own chain (golden fixture) replayed with its
+                    variates; posterior summaries                            1e-6 rel
+                    (north-star bar; the observed error is ~1e-15)
+  T3 distributional on-device Philox variates vs the oracle with numpy variates,
+                    within 5 Monte-Carlo standard errors
+"""
+import numpy as np
+import pytest
+
+from gpu_common import golden_case, gpu_ctx, replay_inputs
+from oracle import bmc_oracle as O
+from pybmc_amd.chains import posterior_summary
+from pybmc_amd.synthetic import synth_problem
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["gibbs_tiny3x2", "gibbs_dense64x8", "gibbs_ortho629x3", "gibbs_ragged1237x5",
+         "gibbs_c2_10000x32"]
+REL_BAR = 1e-6      # north-star tolerance on posterior summaries (float64)
+STEP_TOL = 1e-12    # T1
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_t1_stepwise(name):
+    ctx = gpu_ctx()
+    g, y, X, prior = golden_case(name)
+    Xf = np.asarray(X, float)
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    Xa = np.column_stack([Xf, y])
+    assert rel(ctx.gram(), Xa.T @ Xa) < STEP_TOL                    # f64 MFMA Gram
+    st = O.chain_setup(y, Xf, prior)
+    W, lam, s2i = ctx.basis()
+    assert abs(s2i - st["sigma2_init"]) <= STEP_TOL * st["sigma2_init"]
+    for s2 in (st["sigma2_init"], 0.37, 5.0, float(g["samples"][-1, -1] ** 2)):
+        m, c = ctx.conditional_moments(s2)
+        mo, co = O.conditional_moments(st, y, Xf, s2)
+        assert rel(m, mo) < 1e-10 and rel(c, co) < 1e-10           # vs inv() of the oracle
+    betas = g["samples"][:7, :-1]
+    got = ctx.residual_rss(betas)
+    want = np.array([O.residual_rss(y, Xf, b) for b in betas])
+    assert rel(got, want) < STEP_TOL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_t2_replay_whole_chain(name):
+    ctx = gpu_ctx()
+    g, y, X, prior = golden_case(name)
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    T = int(g["T"])
+    st, xi, ref = replay_inputs(ctx, g, y, X, prior, T)
+    out, stats = ctx.gibbs_run(1, T, xi=xi[None], g=g["G"][None, :T])
+    out = out[0]
+    assert np.abs(out - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    Vt_hat = (g["Vt"] / g["S_hat"][:, None]) if "Vt" in g else None
+    a, b = posterior_summary(out, Vt_hat), posterior_summary(ref, Vt_hat)
+    for key in b:
+        assert rel(a[key], b[key]) < REL_BAR, key
+
+
+def test_t2_replay_is_geometry_independent():
+    """Same chain under different launch geometries (groups, waves, LDS-resident or
+    streaming): the reduction order changes, the chain must not (beyond rounding)."""
+    ctx = gpu_ctx()
+    g, y, X, prior = golden_case("gibbs_c2_10000x32")
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    T = 300
+    st, xi, ref = replay_inputs(ctx, g, y, X, prior, T)
+    outs = []
+    for G, W, stream in [(0, 0, 0), (157, 1, 0), (8, 16, 0), (32, 5, 0), (64, 3, 1), (256, 1, 0),
+                         (1, 16, 1)]:
+        ctx.set_tuning(G, W, stream)
+        o, stats = ctx.gibbs_run(1, T, xi=xi[None], g=g["G"][None, :T])
+        assert np.abs(o[0] - ref).max() < 1e-9
+        outs.append(o[0])
+    ctx.set_tuning(0, 0)
+    for o in outs[1:]:
+        assert np.abs(o - outs[0]).max() < 1e-11
+
+
+def test_t2_replay_many_chains_in_one_launch():
+    """Eight copies of the reference chain in one launch (one per XCD): all equal."""
+    ctx = gpu_ctx()
+    g, y, X, prior = golden_case("gibbs_ortho629x3")
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    T = 500
+    st, xi, ref = replay_inputs(ctx, g, y, X, prior, T)
+    out, stats = ctx.gibbs_run(8, T, xi=np.repeat(xi[None], 8, 0), g=np.repeat(g["G"][None, :T], 8, 0))
+    for c in range(8):
+        assert np.abs(out[c] - ref).max() < 1e-9
+    assert stats["n_chains"] == 8
+
+
+def test_t2_float32_storage():
+    """f32 storage of X and y (f64 accumulation): a NEW capability; the tolerance is
+    the storage rounding (1e-5 relative), not the 1e-6 float64 bar."""
+    ctx = gpu_ctx()
+    g, y, X, prior = golden_case("gibbs_ortho629x3")
+    ctx.set_problem(y, X, dtype=np.float32)
+    ctx.set_prior(*prior)
+    T = 1000
+    # innovations are defined against the f32-rounded problem the device actually holds
+    X32, y32 = np.asarray(X, np.float32).astype(float), np.asarray(y, np.float32).astype(float)
+    W, lam, s2i = ctx.basis()
+    Z, G = g["Z"][:T], g["G"][:T]
+    ref = O.gibbs_replay(y32, X32, T, prior, Z, G)
+    st = O.chain_setup(y32, X32, prior)
+    trace = np.concatenate([[st["sigma2_init"]], ref[:, -1] ** 2])
+    xi = O.innovations_in_basis(st, y32, X32, ref, W, lam, trace)
+    out, _ = ctx.gibbs_run(1, T, xi=xi[None], g=G[None])
+    a, b = posterior_summary(out[0]), posterior_summary(ref)
+    for key in b:
+        assert rel(a[key], b[key]) < 1e-5, key
+
+
+def mcse(x):
+    """Monte-Carlo standard error by batch means (50 batches)."""
+    x = np.asarray(x)
+    nb = 50
+    m = x[: len(x) // nb * nb].reshape(nb, -1, *x.shape[1:]).mean(1)
+    return m.std(0, ddof=1) / np.sqrt(nb)
+
+
+def test_t3_device_rng_matches_oracle_distribution():
+    ctx = gpu_ctx()
+    g, y, X, prior = golden_case("gibbs_dense64x8")
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    T = 40000
+    st = O.chain_setup(y, X, prior)
+    Z, G = O.reference_streams(123, 456, T, X.shape[1], O.gamma_shape(st))
+    ref = O.gibbs_replay(y, X, T, prior, Z, G)
+    out, _ = ctx.gibbs_run(4, T, seeds=[11, 12, 13, 14])
+    pooled = out.reshape(-1, out.shape[-1])
+    for stat in (lambda s: s, lambda s: s ** 2):
+        a, b = stat(pooled), stat(ref)
+        se = np.sqrt(mcse(a) ** 2 + mcse(b) ** 2)
+        assert np.all(np.abs(a.mean(0) - b.mean(0)) < 5 * se)
+    # Gelman-Rubin across the four device chains
+    m = out.mean(1)
+    Wv = out.var(1, ddof=1).mean(0)
+    Bv = T * m.var(0, ddof=1)
+    rhat = np.sqrt(((T - 1) / T * Wv + Bv / T) / Wv)
+    assert np.all(rhat < 1.01)
+
+
+def test_chain_depends_on_its_seed_only():
+    """A chain's samples are a function of (problem, prior, seed): running it alone,
+    among other chains, or under another geometry gives the same chain."""
+    ctx = gpu_ctx()
+    p = synth_problem(3000, 9, 8, seed=2)
+    ctx.set_problem(p["y"], p["X"])
+    ctx.set_prior(*p["prior"])
+    T = 400
+    alone, _ = ctx.gibbs_run(1, T, seeds=[77])
+    many, _ = ctx.gibbs_run(5, T, seeds=[5, 77, 6, 77, 8])
+    assert np.array_equal(many[1], many[3])
+    assert np.abs(many[1] - alone[0]).max() < 1e-11
+    assert np.abs(many[0] - many[1]).max() > 1e-3
+    ctx.set_tuning(3, 2)
+    other, _ = ctx.gibbs_run(1, T, seeds=[77])
+    ctx.set_tuning(0, 0)
+    assert np.abs(other[0] - alone[0]).max() < 1e-11
+    again, _ = ctx.gibbs_run(1, T, seeds=[77])
+    assert np.array_equal(again, alone)            # bit-reproducible run to run
+
+
+def test_more_chains_than_one_launch_holds():
+    ctx = gpu_ctx()
+    p = synth_problem(2000, 6, 5, seed=4)
+    ctx.set_problem(p["y"], p["X"])
+    ctx.set_prior(*p["prior"])
+    out, stats = ctx.gibbs_run(19, 200, seeds=np.arange(19) + 1)
+    assert stats["launches"] >= 3 and np.isfinite(out).all()
+    solo, _ = ctx.gibbs_run(1, 200, seeds=[19])
+    assert np.abs(out[18] - solo[0]).max() < 1e-11
+
+
+# ---------------------------------------------------------------- edge cases
+def test_edge_shapes():
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(0)
+    for n, k in [(1, 1), (2, 1), (63, 2), (64, 3), (65, 3), (129, 7), (4097, 64), (700, 65),
+                 (600, 130)]:
+        X = rng.standard_normal((n, k))
+        y = rng.standard_normal(n)
+        if n < k:
+            continue
+        prior = (np.zeros(k), np.eye(k), 1.0, 1.0)
+        ctx.set_problem(y, X)
+        if n == k == 1:
+            pass
+        ctx.set_prior(*prior)
+        st = O.chain_setup(y, X, prior)
+        T = 50
+        Z, G = O.reference_streams(1, 2, T, k, O.gamma_shape(st))
+        ref = O.gibbs_replay(y, X, T, prior, Z, G)
+        W, lam, s2i = ctx.basis()
+        trace = np.concatenate([[st["sigma2_init"]], ref[:, -1] ** 2])
+        xi = O.innovations_in_basis(st, y, X, ref, W, lam, trace)
+        out, _ = ctx.gibbs_run(1, T, xi=xi[None], g=G[None])
+        assert np.abs(out[0] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()), (n, k)
+
+
+def test_zero_iterations_and_layouts():
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((300, 4))
+    y = rng.standard_normal(300)
+    prior = (np.zeros(4), np.eye(4), 1.0, 1.0)
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    out, _ = ctx.gibbs_run(1, 0, seeds=[1])
+    assert out.shape == (1, 0, 5)
+    a, _ = ctx.gibbs_run(1, 100, seeds=[3])
+    ctx.set_problem(y, np.asfortranarray(X))       # column-major, what U_hat is
+    ctx.set_prior(*prior)
+    b, _ = ctx.gibbs_run(1, 100, seeds=[3])
+    assert np.array_equal(a, b)
+    ctx.set_problem(y, X[:, ::-1][:, ::-1])        # a non-contiguous view is copied
+    ctx.set_prior(*prior)
+    c, _ = ctx.gibbs_run(1, 100, seeds=[3])
+    assert np.array_equal(a, c)
+
+
+def test_error_behaviour_matches_the_reference():
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((50, 3))
+    y = rng.standard_normal(50)
+    ctx.set_problem(y, X)
+    with pytest.raises(np.linalg.LinAlgError):     # inv(b_mean_cov), inference_utils.py:22
+        ctx.set_prior(np.zeros(3), np.zeros((3, 3)), 1.0, 1.0)
+    Xs = np.column_stack([X[:, 0], X[:, 0], X[:, 1]])
+    ctx.set_problem(y, Xs)
+    with pytest.raises(np.linalg.LinAlgError):     # inv(X'X), inference_utils.py:26
+        ctx.set_prior(np.zeros(3), np.eye(3), 1.0, 1.0)
+    with pytest.raises(ValueError):
+        ctx.set_problem(y[:10], X)
+    with pytest.raises(ValueError):
+        ctx.set_prior(np.zeros(2), np.eye(2), 1.0, 1.0)
+    ctx.set_problem(y, X)
+    from pybmc_amd import _lib
+    with pytest.raises(_lib.BmcError):             # run before set_prior
+        ctx.gibbs_run(1, 10, seeds=[1])
+    ctx.set_prior(np.zeros(3), np.eye(3), 1.0, 1.0)
+    with pytest.raises(ValueError):
+        ctx.gibbs_run(0, 10, seeds=[])
+
+
+def test_sigma2_floor():
+    """A perfect fit drives sigma2 to the 1e-6 floor of inference_utils.py:37,52."""
+    ctx = gpu_ctx()
+    X = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+    y = X @ np.array([1.0, 2.0])
+    ctx.set_problem(y, X)
+    ctx.set_prior(np.zeros(2), np.eye(2) * 1e6, 1e-9, 1e-9)
+    _, _, s2i = ctx.basis()
+    assert s2i == 1e-6
+    out, _ = ctx.gibbs_run(1, 50, seeds=[1])
+    assert np.all(out[0, :, -1] >= 1e-3 - 1e-18)   # sigma >= sqrt(1e-6)
+
+
+# ------------------------------------------------------- full-size properties
+def test_full_size_c2_properties():
+    """BASELINE config C2/C3 at full length (8 chains x 50000): size-independent
+    properties -- chains agree (R-hat), the posterior mean of beta equals the
+    closed-form conditional mean at the posterior-mean precision, weights sum to 1."""
+    ctx = gpu_ctx()
+    p = synth_problem(10000, 33, 32, seed=0)
+    ctx.set_problem(p["y"], p["X"])
+    ctx.set_prior(*p["prior"])
+    T = 50000
+    out, stats = ctx.gibbs_run(8, T, seeds=np.arange(1, 9))
+    assert np.isfinite(out).all() and stats["lds_resident"] == 1
+    burn = 1000
+    s = out[:, burn:]
+    m = s.mean(1)
+    Wv = s.var(1, ddof=1).mean(0)
+    Bv = s.shape[1] * m.var(0, ddof=1)
+    rhat = np.sqrt(((s.shape[1] - 1) / s.shape[1] * Wv + Bv / s.shape[1]) / Wv)
+    assert np.all(rhat < 1.005)
+    pooled = s.reshape(-1, 33)
+    # E[beta] = E[ mean(beta | sigma2) ]: average the closed form over the sigma2 draws
+    sig2 = pooled[::997, -1] ** 2
+    means = np.mean([ctx.conditional_moments(v)[0] for v in sig2], axis=0)
+    se = pooled[:, :-1].std(0) / np.sqrt(len(pooled) / 2)
+    assert np.all(np.abs(pooled[:, :-1].mean(0) - means) < 6 * se)
+    Vt_hat = p["Vt"] / p["S_hat"][:, None]
+    w = posterior_summary(pooled, Vt_hat)["weights_mean"]
+    assert abs(w.sum() - 1.0) < 1e-9
+    assert abs(pooled[:, -1].mean() - 0.1) < 0.005
