@@ -148,13 +148,14 @@ def main():
                        "parallelism": f"chain-per-gpu x{world}",
                        "groups_per_chain": st["groups_per_chain"],
                        "waves_per_group": st["waves_per_group"],
-                       "lds_resident": bool(st["lds_resident"])},
+                       "residency": {1: "vgpr", 2: "lds", 3: "stream"}.get(st["residency"]),
+                       "xcd_local_exchange": bool(st["xcd_local_chains"])},
             "roofline": {"bound": "hbm", "kernel": "gibbs_loop_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,
                          "note": "algorithmic bytes (N*K+N)*8 per iteration x iterations / "
                                  "HIP-event time of the loop kernel; at this size the panels are "
-                                 "LDS-resident so HBM traffic is ~0 (see DESIGN.md)",
+                                 "register/LDS-resident so HBM traffic is ~0 (see DESIGN.md)",
                          "loop_ms_per_launch": avg_loop_ms,
                          "us_per_iteration": avg_loop_ms * 1e3 / T},
         }

@@ -47,8 +47,10 @@ enum { BMC_RNG_DEVICE = 0, BMC_RNG_REPLAY = 1 };
 typedef struct {
     int32_t groups_per_chain; /* workgroups that share one chain's rows        */
     int32_t waves_per_group;  /* 1..16 (workgroup = 64 * waves threads)        */
-    int32_t force_streaming;  /* 1 = never pin the panels in LDS               */
-    int32_t chains_per_pass;  /* chains served by one read of X (1,2,4,8)      */
+    int32_t residency;        /* 0 auto, 1 registers, 2 LDS, 3 stream from HBM */
+    int32_t panels_per_wave;  /* register residency: 1, 2 or 4                 */
+    int32_t force_agent_scope;/* 1 = never use the XCD-local (L2) exchange     */
+    int32_t chains_per_pass;  /* reserved                                      */
 } bmc_tuning;
 
 /* Filled by bmc_gibbs_run*.  Times are HIP-event times on the context's stream. */
@@ -63,7 +65,8 @@ typedef struct {
     int32_t groups_per_chain;
     int32_t waves_per_group;
     int32_t chains_per_pass;
-    int32_t lds_resident;     /* 1 = row panels pinned in LDS for the run      */
+    int32_t residency;        /* 1 registers, 2 LDS, 3 streamed                */
+    int32_t xcd_local_chains; /* chains whose groups were verified on one XCD  */
     int64_t bytes_per_pass;   /* algorithmic: (N*K + N) * sizeof(storage)      */
     int64_t passes;           /* X passes executed in total                    */
 } bmc_stats;

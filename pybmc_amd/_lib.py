@@ -24,7 +24,8 @@ BMC_RNG_DEVICE, BMC_RNG_REPLAY = 0, 1
 
 class Tuning(C.Structure):
     _fields_ = [("groups_per_chain", C.c_int32), ("waves_per_group", C.c_int32),
-                ("force_streaming", C.c_int32), ("chains_per_pass", C.c_int32)]
+                ("residency", C.c_int32), ("panels_per_wave", C.c_int32),
+                ("force_agent_scope", C.c_int32), ("chains_per_pass", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -32,7 +33,8 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double), ("iterations", C.c_int64), ("n_chains", C.c_int32),
                 ("launches", C.c_int32), ("groups_per_chain", C.c_int32),
                 ("waves_per_group", C.c_int32), ("chains_per_pass", C.c_int32),
-                ("lds_resident", C.c_int32), ("bytes_per_pass", C.c_int64),
+                ("residency", C.c_int32), ("xcd_local_chains", C.c_int32),
+                ("bytes_per_pass", C.c_int64),
                 ("passes", C.c_int64)]
 
     def as_dict(self):
@@ -141,9 +143,11 @@ class Context:
     def set_stream(self, hip_stream_ptr):
         self._check(self._lib.bmc_set_stream(self._h, _P(hip_stream_ptr or 0)))
 
-    def set_tuning(self, groups_per_chain=0, waves_per_group=0, force_streaming=0,
-                   chains_per_pass=0):
-        t = Tuning(groups_per_chain, waves_per_group, force_streaming, chains_per_pass)
+    def set_tuning(self, groups_per_chain=0, waves_per_group=0, residency=0, panels_per_wave=0,
+                   force_agent_scope=0):
+        """residency: 0 auto, 1 registers, 2 LDS, 3 stream from HBM."""
+        t = Tuning(groups_per_chain, waves_per_group, residency, panels_per_wave,
+                   force_agent_scope, 0)
         self._check(self._lib.bmc_set_tuning(self._h, C.byref(t)))
 
     # -- problem / prior ---------------------------------------------------------

@@ -32,7 +32,7 @@ struct bmc_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    bmc_tuning tune{0, 0, 0, 0};
+    bmc_tuning tune{0, 0, 0, 0, 0, 0};
     int n_cu = 256;
 
     // problem
@@ -50,7 +50,7 @@ struct bmc_ctx {
     // scratch
     DevBuf gramScratch, gramOut, rssPartial, rssOut, coef, stage;
     // run buffers
-    DevBuf xi, gam, uout, samples, gran, status, seeds;
+    DevBuf xi, gam, uout, samples, gran, status, seeds, dbg, placement;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -173,51 +173,83 @@ int rss_on_raw(bmc_ctx* c, const double* coef_host, int32_t nb, double* out_host
 }
 
 struct Geometry {
-    int chains_per_launch, G, waves, ppg, resident;
+    int chains_per_launch, G, waves, ppg, mode, ppw, nslot;
 };
 
-// Pick the launch geometry: as many chains per launch as stay LDS-resident with
-// one workgroup per CU; ~4 waves per workgroup.
+constexpr int RES_AUTO = 0, RES_REG = 1, RES_STREAM = 3;  // 2 = LDS
+constexpr int XCD_COUNT = 8, CU_PER_XCD = 32;
+
+// Pick the launch geometry.  Preference order: row panels in VGPRs with each chain on
+// one XCD (8 slots x <= 32 groups), then panels pinned in LDS, then streaming.
 Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
     const int RP = 64 * c->vec;
     const size_t es = c->f32 ? 4 : 8;
     const size_t panel_bytes = (size_t)(c->k + 1) * RP * es;
-    const size_t fixed = (size_t)((c->k + 2) / 2 * 2) * 8 * 4 + 20 * 8 + 64;
+    const size_t fixed = (size_t)((c->k + 63) / 64 * 64) * 8 * 4 + 20 * 8 + 64;
     const int NP = c->npanels;
-    auto resident_at = [&](int G) {
+    const bmc_tuning& tu = c->tune;
+    auto lds_fits = [&](int G) {
         const int ppg = (NP + G - 1) / G;
         return fixed + (size_t)ppg * panel_bytes <= LDS_LIMIT;
     };
     Geometry g{};
-    const int t_waves = c->tune.waves_per_group;
-    if (c->tune.groups_per_chain > 0) {
-        g.G = c->tune.groups_per_chain;
-        if (g.G > MAX_GROUPS_PER_LAUNCH) g.G = MAX_GROUPS_PER_LAUNCH;
-        g.chains_per_launch = MAX_GROUPS_PER_LAUNCH / g.G;
-        if (g.chains_per_launch > n_chains) g.chains_per_launch = n_chains;
-        if (g.chains_per_launch < 1) g.chains_per_launch = 1;
+    g.ppw = 1;
+    // ---- register residency: G <= 32 groups of <= 8 waves, 1/2/4 panels per wave ----
+    if ((tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec == 1) {
+        for (int ppw : {1, 2, 4}) {
+            if (tu.panels_per_wave > 0 && tu.panels_per_wave != ppw) continue;
+            if (!gibbs_reg_capacity(c->k, c->f32, ppw)) continue;
+            int waves = tu.waves_per_group > 0 ? tu.waves_per_group : 8;
+            if (waves > 8) waves = 8;
+            int G = tu.groups_per_chain > 0 ? tu.groups_per_chain
+                                            : (NP + waves * ppw - 1) / (waves * ppw);
+            if (G > CU_PER_XCD || (int64_t)G * waves * ppw < NP) continue;
+            if (tu.waves_per_group <= 0) {  // spread the panels evenly over the groups
+                const int ppg = (NP + G - 1) / G;
+                waves = (ppg + ppw - 1) / ppw;
+            }
+            g.mode = 0;
+            g.ppw = ppw;
+            g.G = G;
+            g.waves = waves;
+            g.nslot = XCD_COUNT;
+            g.chains_per_launch = n_chains < XCD_COUNT ? n_chains : XCD_COUNT;
+            g.ppg = (NP + G - 1) / G;
+            return g;
+        }
+    }
+    // ---- LDS residency or streaming ------------------------------------------------------
+    const int t_waves = tu.waves_per_group;
+    int cpl = n_chains < XCD_COUNT ? n_chains : XCD_COUNT;
+    int G;
+    if (tu.groups_per_chain > 0) {
+        G = tu.groups_per_chain;
+        if (G > MAX_GROUPS_PER_LAUNCH) G = MAX_GROUPS_PER_LAUNCH;
+        if (cpl > MAX_GROUPS_PER_LAUNCH / G) cpl = MAX_GROUPS_PER_LAUNCH / G;
+        if (cpl < 1) cpl = 1;
     } else {
-        int cpl = n_chains < 8 ? n_chains : 8;
         // fewer chains per launch until the panels fit in LDS (or one chain is left)
-        while (cpl > 1 && !resident_at(MAX_GROUPS_PER_LAUNCH / cpl)) --cpl;
-        g.chains_per_launch = cpl;
+        while (cpl > 1 && !lds_fits(MAX_GROUPS_PER_LAUNCH / cpl)) --cpl;
         const int gmax = MAX_GROUPS_PER_LAUNCH / cpl;
         const int want_waves = t_waves > 0 ? t_waves : 4;
-        int G = (NP + want_waves - 1) / want_waves;  // ~want_waves panels per group
+        G = (NP + want_waves - 1) / want_waves;
         if (G > gmax) G = gmax;
         if (G < 1) G = 1;
-        if (!resident_at(G) && resident_at(gmax)) {
-            while (!resident_at(G)) ++G;
-        }
-        g.G = G;
+        if (!lds_fits(G) && lds_fits(gmax))
+            while (!lds_fits(G)) ++G;
     }
-    if (g.G > NP) g.G = NP;
-    g.ppg = (NP + g.G - 1) / g.G;
-    g.resident = !c->tune.force_streaming && resident_at(g.G);
-    int waves = t_waves > 0 ? t_waves : (g.ppg < 4 ? g.ppg : (g.resident ? (g.ppg < 8 ? g.ppg : 8) : 8));
+    if (G > NP) G = NP;
+    g.G = G;
+    g.chains_per_launch = cpl;
+    g.ppg = (NP + G - 1) / G;
+    const bool want_stream = tu.residency == RES_STREAM;
+    g.mode = (!want_stream && lds_fits(G)) ? 1 : 2;
+    int waves = t_waves > 0 ? t_waves : (g.ppg < 4 ? g.ppg : (g.mode == 1 ? (g.ppg < 8 ? g.ppg : 8) : 8));
     if (waves > 16) waves = 16;
     if (waves < 1) waves = 1;
     g.waves = waves;
+    // one slot per XCD while a chain's groups fit one XCD's CUs; otherwise any placement
+    g.nslot = (G <= CU_PER_XCD) ? XCD_COUNT : cpl;
     return g;
 }
 
@@ -250,8 +282,10 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     }
     const Geometry geo = choose_geometry(c, n_chains);
     const int gran_stride = ((2 * geo.G + 31) / 32) * 32;
-    if ((rc = ensure(c, c->gran, (size_t)geo.chains_per_launch * 2 * gran_stride * 8))) return rc;
+    if ((rc = ensure(c, c->gran, (size_t)geo.chains_per_launch * 3 * gran_stride * 8))) return rc;
     if ((rc = ensure(c, c->status, C * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->placement, C * sizeof(int32_t)))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->placement.p, 0, C * sizeof(int32_t), c->stream));
     if ((rc = ensure(c, c->seeds, C * sizeof(uint64_t)))) return rc;
 
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, C * sizeof(int32_t), c->stream));
@@ -283,8 +317,17 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     a.iters = iters;
     a.G = geo.G;
     a.waves = geo.waves;
-    a.resident = geo.resident;
+    a.mode = geo.mode;
+    a.reg_ppw = geo.ppw;
+    a.nslot = geo.nslot;
+    a.force_agent_scope = c->tune.force_agent_scope;
     a.panels_per_group = geo.ppg;
+    a.dbg = nullptr;
+#ifdef BMC_STAMPS
+    if ((rc = ensure(c, c->dbg, 8 * sizeof(long long)))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 8 * sizeof(long long), c->stream));
+    a.dbg = (long long*)c->dbg.p;
+#endif
     int launches = 0;
     for (int c0 = 0; iters > 0 && c0 < n_chains; c0 += geo.chains_per_launch) {
         const int m = n_chains - c0 < geo.chains_per_launch ? n_chains - c0 : geo.chains_per_launch;
@@ -293,7 +336,8 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         a.gam = (const double*)c->gam.p + (size_t)c0 * T;
         a.uout = (double*)c->uout.p + (size_t)c0 * T * (K + 1);
         a.status = (int32_t*)c->status.p + c0;
-        HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)m * 2 * gran_stride * 8, c->stream));
+        a.placement = (int32_t*)c->placement.p + c0;
+        HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)m * 3 * gran_stride * 8, c->stream));
         if (gibbs_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
         HIPCHK(c, launch_gibbs(a, c->stream));
         ++launches;
@@ -303,9 +347,11 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         HIPCHK(c, launch_unrotate((const double*)c->uout.p, (const double*)c->dWT.p, K,
                                   (int64_t)(C * T), d_samples, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    std::vector<int32_t> st(C, 0);
+    std::vector<int32_t> st(C, 0), place(C, 0);
     HIPCHK(c, hipMemcpyAsync(st.data(), c->status.p, C * sizeof(int32_t), hipMemcpyDeviceToHost,
                              c->stream));
+    HIPCHK(c, hipMemcpyAsync(place.data(), c->placement.p, C * sizeof(int32_t),
+                             hipMemcpyDeviceToHost, c->stream));
     if (samples_host && iters > 0)
         HIPCHK(c, hipMemcpyAsync(samples_host, d_samples, C * T * (K + 1) * 8,
                                  hipMemcpyDeviceToHost, c->stream));
@@ -323,7 +369,9 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         stats->groups_per_chain = geo.G;
         stats->waves_per_group = geo.waves;
         stats->chains_per_pass = 1;
-        stats->lds_resident = geo.resident;
+        stats->residency = geo.mode + 1;
+        stats->xcd_local_chains = 0;
+        for (size_t i = 0; i < C; ++i) stats->xcd_local_chains += place[i] ? 1 : 0;
         stats->bytes_per_pass = ((int64_t)c->n * K + c->n) * (c->f32 ? 4 : 8);
         stats->passes = (int64_t)n_chains * iters;
     }
@@ -375,7 +423,7 @@ void bmc_destroy(bmc_ctx* c) {
     for (DevBuf* b : {&c->Xraw, &c->Yp, &c->Xrot, &c->dW, &c->dWT, &c->dLam, &c->dC1, &c->dC2,
                       &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef,
                       &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
-                      &c->seeds})
+                      &c->seeds, &c->dbg, &c->placement})
         release(*b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -403,12 +451,15 @@ int bmc_set_stream(bmc_ctx* c, void* hip_stream) {
 int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
     if (!c) return BMC_EINVAL;
     if (!t) {
-        c->tune = bmc_tuning{0, 0, 0, 0};
+        c->tune = bmc_tuning{0, 0, 0, 0, 0, 0};
         return BMC_OK;
     }
     if (t->groups_per_chain < 0 || t->groups_per_chain > 256 || t->waves_per_group < 0 ||
-        t->waves_per_group > 16)
-        return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..16)");
+        t->waves_per_group > 16 || t->residency < 0 || t->residency > 3 ||
+        (t->panels_per_wave != 0 && t->panels_per_wave != 1 && t->panels_per_wave != 2 &&
+         t->panels_per_wave != 4))
+        return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..16, residency 0..3, "
+                                   "panels_per_wave 0/1/2/4)");
     c->tune = *t;
     return BMC_OK;
 }
@@ -659,6 +710,15 @@ int bmc_rng_fill(bmc_ctx* c, uint64_t seed, int64_t count_normal, double* normal
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BMC_OK;
 }
+
+#ifdef BMC_STAMPS
+// Diagnostic build only; not part of the public ABI.
+int bmc_dev_get_stamps(bmc_ctx* c, long long* out8) {
+    if (!c || !out8 || !c->dbg.p) return BMC_EINVAL;
+    HIPCHK(c, hipMemcpy(out8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return BMC_OK;
+}
+#endif
 
 int bmc_philox_raw(bmc_ctx* c, uint64_t seed, uint32_t stream_id, int64_t nblocks4, uint32_t* out) {
     if (!c) return BMC_EINVAL;

@@ -59,17 +59,23 @@ struct GibbsArgs {
     const double* xi;       // [C][T][k]
     const double* gam;      // [C][T]
     double* uout;           // [C][T][k+1]
-    unsigned long long* gran;  // [C][2][gran_stride] granules, zeroed before launch
+    unsigned long long* gran;  // [C][3][gran_stride]: 2 parities of granules + XCC words, zeroed
     int32_t gran_stride;    // u64 words per (chain, parity), >= 2*G, multiple of 32
     int32_t* status;        // [C] 0 ok, 1 timeout
     int64_t iters;
     int32_t n_chains;       // chains in THIS launch
     int32_t G;              // workgroups per chain
     int32_t waves;          // waves per workgroup
-    int32_t resident;       // panels pinned in LDS
+    int32_t mode;           // 0 registers, 1 LDS, 2 streaming
+    int32_t reg_ppw;        // panels per wave (register mode)
+    int32_t nslot;          // grid = nslot x G; 8 = one slot per XCD, else = n_chains
+    int32_t force_agent_scope;  // 1: never use the XCD-local exchange
+    int32_t* placement;     // [C] out: 1 = chain verified on one XCD (L2-local exchange)
     int32_t panels_per_group;  // max panels a group owns
+    long long* dbg;         // diagnostic builds only (-DBMC_STAMPS); NULL otherwise
 };
 size_t gibbs_lds_bytes(const GibbsArgs& a);
+int gibbs_reg_capacity(int k, int f32, int ppw);  // 1 if ppw panels of k columns fit in VGPRs
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s);
 
 }  // namespace bmc

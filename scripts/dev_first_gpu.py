@@ -41,7 +41,7 @@ ctx.set_problem(p["y"], p["X"]); ctx.set_prior(*p["prior"])
 for G, Wv in [(0,0),(40,4),(157,1),(79,2),(32,5),(20,8),(16,10)]:
     ctx.set_tuning(G, Wv)
     out, stats = ctx.gibbs_run(1, 20000, seeds=[1])
-    print("C2 1 chain", G, Wv, "loop_ms", stats["loop_ms"], "us/iter", stats["loop_ms"]*1e3/20000, "rng", stats["rng_ms"], "post", stats["post_ms"], "res", stats["lds_resident"], stats["groups_per_chain"], stats["waves_per_group"])
+    print("C2 1 chain", G, Wv, "loop_ms", stats["loop_ms"], "us/iter", stats["loop_ms"]*1e3/20000, "rng", stats["rng_ms"], "post", stats["post_ms"], "res", stats["residency"], stats["groups_per_chain"], stats["waves_per_group"])
 ctx.set_tuning(0,0)
 out, stats = ctx.gibbs_run(8, 20000, seeds=np.arange(1,9))
 print("C2 8 chains", stats)

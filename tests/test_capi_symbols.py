@@ -39,9 +39,9 @@ def test_python_binding_covers_the_header():
 
 
 def test_struct_layouts_match_the_header():
-    # bmc_stats: 4 doubles, int64, 6 int32, 2 int64 -> 8-byte aligned, 80 bytes
-    assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 8 + 6 * 4 + 2 * 8
-    assert ctypes.sizeof(_lib.Tuning) == 16
+    # bmc_stats: 4 doubles, int64, 7 int32 (+4 pad), 2 int64 -> 8-byte aligned
+    assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 8 + 8 * 4 + 2 * 8
+    assert ctypes.sizeof(_lib.Tuning) == 24
 
 
 def test_missing_library_fails_loudly(monkeypatch):

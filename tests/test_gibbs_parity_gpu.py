@@ -78,12 +78,20 @@ def test_t2_replay_is_geometry_independent():
     T = 300
     st, xi, ref = replay_inputs(ctx, g, y, X, prior, T)
     outs = []
-    for G, W, stream in [(0, 0, 0), (157, 1, 0), (8, 16, 0), (32, 5, 0), (64, 3, 1), (256, 1, 0),
-                         (1, 16, 1)]:
-        ctx.set_tuning(G, W, stream)
+    # (groups, waves, residency 1 reg/2 lds/3 stream, panels per wave, force agent scope)
+    seen = set()
+    for G, W, res, ppw, agent in [(0, 0, 0, 0, 0), (0, 0, 0, 0, 1), (20, 8, 1, 1, 0),
+                                  (32, 5, 1, 1, 1), (10, 8, 1, 2, 0), (16, 5, 1, 2, 1),
+                                  (157, 1, 2, 0, 0), (8, 16, 2, 0, 0), (32, 5, 2, 0, 1),
+                                  (64, 3, 3, 0, 0), (256, 1, 2, 0, 0), (1, 16, 3, 0, 0)]:
+        ctx.set_tuning(G, W, res, ppw, agent)
         o, stats = ctx.gibbs_run(1, T, xi=xi[None], g=g["G"][None, :T])
-        assert np.abs(o[0] - ref).max() < 1e-9
+        assert np.abs(o[0] - ref).max() < 1e-9, (G, W, res, ppw, agent)
+        if agent:
+            assert stats["xcd_local_chains"] == 0
+        seen.add((stats["residency"], stats["xcd_local_chains"]))
         outs.append(o[0])
+    assert {1, 2, 3} <= {r for r, _ in seen}
     ctx.set_tuning(0, 0)
     for o in outs[1:]:
         assert np.abs(o - outs[0]).max() < 1e-11
@@ -169,7 +177,7 @@ def test_chain_depends_on_its_seed_only():
     assert np.array_equal(many[1], many[3])
     assert np.abs(many[1] - alone[0]).max() < 1e-11
     assert np.abs(many[0] - many[1]).max() > 1e-3
-    ctx.set_tuning(3, 2)
+    ctx.set_tuning(3, 2, 2)
     other, _ = ctx.gibbs_run(1, T, seeds=[77])
     ctx.set_tuning(0, 0)
     assert np.abs(other[0] - alone[0]).max() < 1e-11
@@ -284,7 +292,7 @@ def test_full_size_c2_properties():
     ctx.set_prior(*p["prior"])
     T = 50000
     out, stats = ctx.gibbs_run(8, T, seeds=np.arange(1, 9))
-    assert np.isfinite(out).all() and stats["lds_resident"] == 1
+    assert np.isfinite(out).all() and stats["residency"] == 1
     burn = 1000
     s = out[:, burn:]
     m = s.mean(1)
