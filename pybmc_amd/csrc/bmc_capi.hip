@@ -48,7 +48,7 @@ struct bmc_ctx {
     DevBuf dW, dWT, dLam, dC1, dC2;
 
     // scratch
-    DevBuf gramScratch, gramOut, rssPartial, rssOut, coef, stage;
+    DevBuf gramScratch, gramOut, rssPartial, rssOut, coef, stage, ticket;
     // run buffers
     DevBuf xi, gam, uout, samples, gran, status, seeds, dbg, placement;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -152,9 +152,18 @@ int check_problem_args(bmc_ctx* c, const void* X, int64_t n, int32_t k, int64_t 
     return BMC_OK;
 }
 
+int ensure_ticket(bmc_ctx* c) {
+    if (c->ticket.p) return BMC_OK;
+    int rc = ensure(c, c->ticket, 64);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->ticket.p, 0, 64, c->stream));  // the kernel keeps it zero
+    return BMC_OK;
+}
+
 int rss_on_raw(bmc_ctx* c, const double* coef_host, int32_t nb, double* out_host) {
     const Panels P = panels_of(c, c->Xraw.p);
     int rc;
+    if ((rc = ensure_ticket(c))) return rc;
     if ((rc = ensure(c, c->rssPartial, (size_t)rss_groups(P) * 8 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->rssOut, 8 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->coef, (size_t)8 * c->k * sizeof(double)))) return rc;
@@ -164,7 +173,7 @@ int rss_on_raw(bmc_ctx* c, const double* coef_host, int32_t nb, double* out_host
                                  (size_t)m * c->k * sizeof(double), hipMemcpyHostToDevice,
                                  c->stream));
         HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p, m, (double*)c->rssPartial.p,
-                                      (double*)c->rssOut.p, c->stream));
+                                      (unsigned*)c->ticket.p, (double*)c->rssOut.p, c->stream));
         HIPCHK(c, hipMemcpyAsync(out_host + b0, c->rssOut.p, (size_t)m * sizeof(double),
                                  hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -199,15 +208,13 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
         for (int ppw : {1, 2, 4}) {
             if (tu.panels_per_wave > 0 && tu.panels_per_wave != ppw) continue;
             if (!gibbs_reg_capacity(c->k, c->f32, ppw)) continue;
-            int waves = tu.waves_per_group > 0 ? tu.waves_per_group : 8;
-            if (waves > 8) waves = 8;
+            // all 32 CUs of the XCD (measured: 32 groups x 5 waves beats 20 x 8 at C2)
             int G = tu.groups_per_chain > 0 ? tu.groups_per_chain
-                                            : (NP + waves * ppw - 1) / (waves * ppw);
-            if (G > CU_PER_XCD || (int64_t)G * waves * ppw < NP) continue;
-            if (tu.waves_per_group <= 0) {  // spread the panels evenly over the groups
-                const int ppg = (NP + G - 1) / G;
-                waves = (ppg + ppw - 1) / ppw;
-            }
+                                            : (NP < CU_PER_XCD ? NP : CU_PER_XCD);
+            if (G > CU_PER_XCD) continue;
+            const int ppg_reg = (NP + G - 1) / G;
+            int waves = tu.waves_per_group > 0 ? tu.waves_per_group : (ppg_reg + ppw - 1) / ppw;
+            if (waves > 8 || (int64_t)G * waves * ppw < NP) continue;
             g.mode = 0;
             g.ppw = ppw;
             g.G = G;
@@ -421,7 +428,7 @@ void bmc_destroy(bmc_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->Xraw, &c->Yp, &c->Xrot, &c->dW, &c->dWT, &c->dLam, &c->dC1, &c->dC2,
-                      &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef,
+                      &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef, &c->ticket,
                       &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
                       &c->seeds, &c->dbg, &c->placement})
         release(*b);
@@ -652,16 +659,17 @@ int bmc_residual_rss_bench(bmc_ctx* c, int32_t nb, int32_t reps, double* ms_per_
     if ((rc = ensure(c, c->rssPartial, (size_t)rss_groups(P) * 8 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->rssOut, 8 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->coef, (size_t)8 * c->k * sizeof(double)))) return rc;
+    if ((rc = ensure_ticket(c))) return rc;
     std::vector<double> cf((size_t)nb * c->k);
     for (size_t i = 0; i < cf.size(); ++i) cf[i] = 0.01 * (double)((i * 2654435761u) % 97) - 0.5;
     HIPCHK(c, hipMemcpyAsync(c->coef.p, cf.data(), cf.size() * 8, hipMemcpyHostToDevice, c->stream));
     for (int i = 0; i < 3; ++i)
         HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p, nb, (double*)c->rssPartial.p,
-                                      (double*)c->rssOut.p, c->stream));
+                                      (unsigned*)c->ticket.p, (double*)c->rssOut.p, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     for (int i = 0; i < reps; ++i)
         HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p, nb, (double*)c->rssPartial.p,
-                                      (double*)c->rssOut.p, c->stream));
+                                      (unsigned*)c->ticket.p, (double*)c->rssOut.p, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0;

@@ -30,11 +30,13 @@ hipError_t launch_gram(const Panels& P, void* scratch, double* gram_out, hipStre
 // Xrot = X * W (W k x k row-major, device), same panel layout and storage type.
 hipError_t launch_rotate(const Panels& P, const double* W, void* Xrot, hipStream_t s);
 
-// rss[b] = sum_i (y_i - sum_j X_ij coef[b][j])^2, b < nb (nb <= 8).
-// partial: >= rss_partial_doubles(P) * nb doubles of scratch.
+// rss[b] = sum_i (y_i - sum_j X_ij coef[b][j])^2, b < nb (nb <= 8), one launch.
+// partial: >= rss_groups(P) * 8 doubles of scratch; ticket_word: one zeroed u32 that
+// the kernel leaves zero again.
 int32_t rss_groups(const Panels& P);
 hipError_t launch_residual_rss(const Panels& P, const double* coef, int32_t nb,
-                               double* partial, double* rss_out, hipStream_t s);
+                               double* partial, unsigned* ticket_word, double* rss_out,
+                               hipStream_t s);
 
 // samples[c][t][0..k) = W u[c][t][0..k);  samples[c][t][k] = u[c][t][k]
 hipError_t launch_unrotate(const double* uout, const double* W, int32_t k, int64_t rows,
