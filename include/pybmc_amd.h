@@ -137,6 +137,28 @@ int bmc_gibbs_run(bmc_ctx* ctx, int32_t n_chains, int64_t iters, const uint64_t*
 int bmc_gibbs_run_device(bmc_ctx* ctx, int32_t n_chains, int64_t iters,
                          const uint64_t* seeds, void* d_samples_out, bmc_stats* stats);
 
+/* ---- posterior predictive -----------------------------------------------------
+ * Replaces rndm_m_random_calculator, pybmc/sampling_utils.py:40-84 (callers
+ * pybmc/bmc.py:227,323,367), and the interval test of coverage, :24-34.
+ *   theta   [n_draws][k+1]   the posterior rows the caller selected (:57; the reference
+ *                            draws 10000 of them without replacement), last column sigma
+ *   weights = theta[:, :k] Vt_hat + 1/n_models                               (:60-67)
+ *   rndm_m[s][p] = weights[s] . preds[p] + z[s][p] sigma_s                   (:70-77)
+ * rng_mode BMC_RNG_DEVICE: z from the Philox generator keyed by seed (noise = NULL);
+ * BMC_RNG_REPLAY: noise is [n_draws][n_points] row-major standard normals.
+ * Order statistics: for each of n_q requests, numpy's linear interpolation between
+ * sorted[q_index] and sorted[q_index+1] with weight q_gamma (:80-82); bands_out is
+ * [n_q][n_points].  Coverage (optional, truth != NULL): hits[c] counts the points with
+ * sorted[cov_lo[c]] <= truth <= sorted[cov_hi[c]]; n_q, n_cov <= 64; n_draws <= 16384.
+ * rndm_m_out (optional) is [n_points][n_draws]: the reference's (n_draws, n_points)
+ * array in Fortran order. */
+int bmc_predict(bmc_ctx* ctx, const double* preds, int64_t n_points, int32_t n_models,
+                const double* theta, int32_t n_draws, int32_t k, const double* Vt_hat,
+                int rng_mode, uint64_t seed, const double* noise,
+                const int32_t* q_index, const double* q_gamma, int32_t n_q,
+                const double* truth, const int32_t* cov_lo, const int32_t* cov_hi,
+                int32_t n_cov, double* rndm_m_out, double* bands_out, int64_t* cov_hits_out);
+
 /* ---- on-device variates (exposed so the generator itself can be tested) ----
  * normals_out [count_normal] ~ N(0,1); gammas_out [count_gamma] ~ Gamma(shape,1). */
 int bmc_rng_fill(bmc_ctx* ctx, uint64_t seed, int64_t count_normal, double* normals_out,

@@ -64,6 +64,10 @@ PROTOTYPES = {
                                 _D, C.POINTER(Stats)]),
     "bmc_gibbs_run_device": (C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_uint64), _P,
                                        C.POINTER(Stats)]),
+    "bmc_predict": (C.c_int, [_P, _D, C.c_int64, C.c_int32, _D, C.c_int32, C.c_int32, _D, C.c_int,
+                              C.c_uint64, _D, C.POINTER(C.c_int32), _D, C.c_int32, _D,
+                              C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _D, _D,
+                              C.POINTER(C.c_int64)]),
     "bmc_rng_fill": (C.c_int, [_P, C.c_uint64, C.c_int64, _D, C.c_double, C.c_int64, _D]),
     "bmc_philox_raw": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(C.c_uint32)]),
 }
@@ -247,6 +251,45 @@ class Context:
             C.byref(st)))
         return st.as_dict()
 
+    # -- posterior predictive --------------------------------------------------------------
+    def predict(self, preds, theta, Vt_hat, seed=0, noise=None, q=(2.5, 50, 97.5), truth=None,
+                cov_percentiles=None, want_draws=True):
+        """preds (M, Km), theta (S, k+1) selected posterior rows, Vt_hat (k, Km).
+        Returns (rndm_m (S, M) Fortran-ordered or None, bands (len(q), M), coverage or None)."""
+        preds = np.ascontiguousarray(preds, dtype=np.float64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        Vt_hat = np.ascontiguousarray(Vt_hat, dtype=np.float64)
+        M, Km = preds.shape
+        S, k1 = theta.shape
+        if Vt_hat.shape != (k1 - 1, Km):
+            raise ValueError("Vt_hat must be (k, n_models) with k = theta.shape[1] - 1")
+        qi, qg = order_stat_plan(S, q)
+        bands = np.empty((len(q), M))
+        lo = hi = hits = None
+        tr = None
+        n_cov = 0
+        if truth is not None:
+            tr = np.ascontiguousarray(truth, dtype=np.float64).reshape(M)
+            lo, hi = coverage_plan(S, cov_percentiles)
+            n_cov = len(lo)
+            hits = np.zeros(n_cov, dtype=np.int64)
+        draws = np.empty((M, S)) if want_draws else None
+        nz = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, dtype=np.float64)
+            if nz.shape != (S, M):
+                raise ValueError("noise must be (n_draws, n_points)")
+        i32p = C.POINTER(C.c_int32)
+        self._check(self._lib.bmc_predict(
+            self._h, _dptr(preds), M, Km, _dptr(theta), S, k1 - 1, _dptr(Vt_hat),
+            BMC_RNG_REPLAY if nz is not None else BMC_RNG_DEVICE, int(seed) & (2 ** 64 - 1),
+            _dptr(nz), qi.ctypes.data_as(i32p), _dptr(qg), len(q), _dptr(tr),
+            lo.ctypes.data_as(i32p) if lo is not None else None,
+            hi.ctypes.data_as(i32p) if hi is not None else None, n_cov, _dptr(draws),
+            _dptr(bands), hits.ctypes.data_as(C.POINTER(C.c_int64)) if hits is not None else None))
+        cov = None if hits is None else [int(h) / M * 100 for h in hits]
+        return (draws.T if draws is not None else None), bands, cov
+
     # -- variates -----------------------------------------------------------------------
     def rng_fill(self, seed, n_normal=0, shape=1.0, n_gamma=0):
         z = np.empty(n_normal)
@@ -260,6 +303,34 @@ class Context:
         self._check(self._lib.bmc_philox_raw(self._h, int(seed), int(stream_id), nblocks4,
                                              out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out.reshape(nblocks4, 4)
+
+
+def order_stat_plan(n, percentiles):
+    """(index, weight) of numpy.percentile's default linear method for each percentile:
+    virtual index (n - 1) * q in float64, as numpy does (reference sampling_utils.py:80-82
+    calls np.percentile)."""
+    idx, gam = [], []
+    for p in percentiles:
+        qq = np.true_divide(np.float64(p), 100)
+        vi = (n - 1) * qq
+        lo = np.floor(vi)
+        g = vi - lo
+        lo = int(lo)
+        if lo >= n - 1:
+            lo, g = n - 1, 0.0
+        if lo < 0:
+            lo, g = 0, 0.0
+        idx.append(lo)
+        gam.append(float(g))
+    return np.array(idx, dtype=np.int32), np.array(gam, dtype=np.float64)
+
+
+def coverage_plan(n, percentiles):
+    """Index pairs of reference sampling_utils.py:30-31 (truncating int())."""
+    lo = [int((0.5 - p / 200) * n) for p in percentiles]
+    hi = [int((0.5 + p / 200) * n) - 1 for p in percentiles]
+    hi = [h if h >= 0 else n + h for h in hi]   # python negative index
+    return np.array(lo, dtype=np.int32), np.array(hi, dtype=np.int32)
 
 
 _default_ctx = {}

@@ -11,7 +11,7 @@ import numpy as np
 import pandas as pd
 
 from .inference_utils import USVt_hat_extraction, gibbs_sampler, gibbs_sampler_simplex
-from .sampling_utils import coverage, rndm_m_random_calculator
+from .sampling_utils import predictive_coverage, rndm_m_random_calculator
 
 
 class BayesianModelCombination:
@@ -188,6 +188,6 @@ class BayesianModelCombination:
                     df = df[df[col].isin(cond)]
                 else:
                     df = df[df[col] == cond]
-        rndm_m, _ = rndm_m_random_calculator(df[self.models].to_numpy(), self.samples,
-                                             self.Vt_hat, device=self.device)
-        return coverage(np.arange(0, 101, 5), rndm_m, df, truth_column=self.truth_column_name)
+        return predictive_coverage(np.arange(0, 101, 5), df[self.models].to_numpy(), self.samples,
+                                   self.Vt_hat, df[self.truth_column_name].to_numpy(),
+                                   device=self.device)

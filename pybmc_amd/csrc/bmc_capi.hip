@@ -51,6 +51,8 @@ struct bmc_ctx {
     DevBuf gramScratch, gramOut, rssPartial, rssOut, coef, stage, ticket;
     // run buffers
     DevBuf xi, gam, uout, samples, gran, status, seeds, dbg, placement;
+    // predictive buffers
+    DevBuf pPreds, pTheta, pVt, pWt, pSig, pR, pNoise, pAux, pBands;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -430,7 +432,8 @@ void bmc_destroy(bmc_ctx* c) {
     for (DevBuf* b : {&c->Xraw, &c->Yp, &c->Xrot, &c->dW, &c->dWT, &c->dLam, &c->dC1, &c->dC2,
                       &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef, &c->ticket,
                       &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
-                      &c->seeds, &c->dbg, &c->placement})
+                      &c->seeds, &c->dbg, &c->placement, &c->pPreds, &c->pTheta, &c->pVt,
+                      &c->pWt, &c->pSig, &c->pR, &c->pNoise, &c->pAux, &c->pBands})
         release(*b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -715,6 +718,95 @@ int bmc_rng_fill(bmc_ctx* c, uint64_t seed, int64_t count_normal, double* normal
     if (count_gamma)
         HIPCHK(c, hipMemcpyAsync(gammas_out, c->gam.p, (size_t)count_gamma * 8,
                                  hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMC_OK;
+}
+
+int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const double* theta,
+                int32_t S, int32_t k, const double* Vt_hat, int rng_mode, uint64_t seed,
+                const double* noise, const int32_t* q_index, const double* q_gamma, int32_t n_q,
+                const double* truth, const int32_t* cov_lo, const int32_t* cov_hi, int32_t n_cov,
+                double* rndm_m_out, double* bands_out, int64_t* cov_hits_out) {
+    if (!c) return BMC_EINVAL;
+    if (!preds || !theta || !Vt_hat) return fail(c, BMC_EINVAL, "preds/theta/Vt_hat must not be NULL");
+    if (M < 1 || Km < 1 || k < 1 || S < 1) return fail(c, BMC_EINVAL, "empty predictive problem");
+    if (S > 16384) return fail(c, BMC_EINVAL, "n_draws > 16384 is not supported");
+    if (n_q < 0 || n_q > 64 || n_cov < 0 || n_cov > 64)
+        return fail(c, BMC_EINVAL, "n_q and n_cov must be in 0..64");
+    if (n_q > 0 && (!q_index || !q_gamma || !bands_out))
+        return fail(c, BMC_EINVAL, "order statistics requested without index/gamma/output");
+    if (n_cov > 0 && (!truth || !cov_lo || !cov_hi || !cov_hits_out))
+        return fail(c, BMC_EINVAL, "coverage requested without truth/bounds/output");
+    if (rng_mode == BMC_RNG_REPLAY ? !noise : noise != nullptr)
+        return fail(c, BMC_EINVAL, "noise must be given exactly in replay mode");
+    if (rng_mode != BMC_RNG_REPLAY && rng_mode != BMC_RNG_DEVICE)
+        return fail(c, BMC_EINVAL, "rng_mode must be 0 or 1");
+    for (int i = 0; i < n_q; ++i)
+        if (q_index[i] < 0 || q_index[i] >= S) return fail(c, BMC_EINVAL, "q_index out of range");
+    for (int i = 0; i < n_cov; ++i)
+        if (cov_lo[i] < 0 || cov_lo[i] >= S || cov_hi[i] < 0 || cov_hi[i] >= S)
+            return fail(c, BMC_EINVAL, "coverage index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    PredictArgs a;
+    a.M = M; a.Km = Km; a.k = k; a.S = S;
+    a.S_pad = (S + 63) / 64 * 64;
+    a.Km_pad = (Km + 3) / 4 * 4;
+    a.seed = seed;
+    a.n_q = n_q; a.n_cov = n_cov;
+    const size_t szP = (size_t)M * Km * 8, szT = (size_t)S * (k + 1) * 8, szV = (size_t)k * Km * 8;
+    int rc;
+    if ((rc = ensure(c, c->pPreds, szP)) || (rc = ensure(c, c->pTheta, szT)) ||
+        (rc = ensure(c, c->pVt, szV)) || (rc = ensure(c, c->pWt, (size_t)a.S_pad * a.Km_pad * 8)) ||
+        (rc = ensure(c, c->pSig, (size_t)a.S_pad * 8)) ||
+        (rc = ensure(c, c->pR, (size_t)M * a.S_pad * 8)) ||
+        (rc = ensure(c, c->pBands, (size_t)(n_q > 0 ? n_q : 1) * M * 8)))
+        return rc;
+    // aux block: q_index[64] i32 | cov_lo[64] | cov_hi[64] | q_gamma[64] f64 | hits[64] u64 | truth[M]
+    const size_t offQ = 0, offLo = 256, offHi = 512, offG = 768, offH = 768 + 512, offT = offH + 512;
+    if ((rc = ensure(c, c->pAux, offT + (size_t)M * 8))) return rc;
+    char* aux = (char*)c->pAux.p;
+    HIPCHK(c, hipMemsetAsync(aux, 0, offT, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pPreds.p, preds, szP, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pTheta.p, theta, szT, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pVt.p, Vt_hat, szV, hipMemcpyHostToDevice, c->stream));
+    if (n_q) {
+        HIPCHK(c, hipMemcpyAsync(aux + offQ, q_index, n_q * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(aux + offG, q_gamma, n_q * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (n_cov) {
+        HIPCHK(c, hipMemcpyAsync(aux + offLo, cov_lo, n_cov * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(aux + offHi, cov_hi, n_cov * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(aux + offT, truth, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    a.noise_replay = nullptr;
+    if (noise) {
+        if ((rc = ensure(c, c->pNoise, (size_t)S * M * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->pNoise.p, noise, (size_t)S * M * 8, hipMemcpyHostToDevice, c->stream));
+        a.noise_replay = (const double*)c->pNoise.p;
+    }
+    a.preds = (const double*)c->pPreds.p;
+    a.theta = (const double*)c->pTheta.p;
+    a.Vt = (const double*)c->pVt.p;
+    a.Wt = (double*)c->pWt.p;
+    a.sig = (double*)c->pSig.p;
+    a.R = (double*)c->pR.p;
+    a.q_index = (const int32_t*)(aux + offQ);
+    a.q_gamma = (const double*)(aux + offG);
+    a.truth = n_cov ? (const double*)(aux + offT) : nullptr;
+    a.cov_lo = (const int32_t*)(aux + offLo);
+    a.cov_hi = (const int32_t*)(aux + offHi);
+    a.bands = (double*)c->pBands.p;
+    a.hits = (unsigned long long*)(aux + offH);
+    HIPCHK(c, launch_predict(a, c->stream));
+    if (n_q)
+        HIPCHK(c, hipMemcpyAsync(bands_out, c->pBands.p, (size_t)n_q * M * 8, hipMemcpyDeviceToHost,
+                                 c->stream));
+    if (n_cov)
+        HIPCHK(c, hipMemcpyAsync(cov_hits_out, aux + offH, (size_t)n_cov * 8, hipMemcpyDeviceToHost,
+                                 c->stream));
+    if (rndm_m_out)
+        HIPCHK(c, hipMemcpy2DAsync(rndm_m_out, (size_t)S * 8, c->pR.p, (size_t)a.S_pad * 8,
+                                   (size_t)S * 8, (size_t)M, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BMC_OK;
 }

@@ -50,6 +50,31 @@ hipError_t launch_rng_fill(const uint64_t* seeds_dev, int32_t n_chains,
 hipError_t launch_philox_raw(uint64_t seed, uint32_t stream, int64_t nblocks4,
                              uint32_t* out, hipStream_t s);
 
+// ---- posterior predictive --------------------------------------------------------
+struct PredictArgs {
+    const double* preds;   // [M][Km]
+    int64_t M;
+    int32_t Km, k, S;      // models, kept components, draws
+    int32_t S_pad, Km_pad; // multiples of 64 and 4
+    const double* theta;   // [S][k+1] selected posterior rows
+    const double* Vt;      // [k][Km]
+    double* Wt;            // [S_pad][Km_pad] scratch
+    double* sig;           // [S_pad] scratch
+    uint64_t seed;
+    const double* noise_replay;  // [S][M] or NULL (device generator)
+    double* R;             // [M][S_pad]
+    const int32_t* q_index;
+    const double* q_gamma;
+    int32_t n_q;
+    const double* truth;   // [M] or NULL
+    const int32_t* cov_lo;
+    const int32_t* cov_hi;
+    int32_t n_cov;
+    double* bands;         // [n_q][M]
+    unsigned long long* hits;  // [n_cov], zeroed
+};
+hipError_t launch_predict(const PredictArgs& a, hipStream_t s);
+
 // ---- the persistent Gibbs loop ------------------------------------------------
 struct GibbsArgs {
     Panels P;               // ROTATED panels
