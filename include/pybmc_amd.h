@@ -137,6 +137,24 @@ int bmc_gibbs_run(bmc_ctx* ctx, int32_t n_chains, int64_t iters, const uint64_t*
 int bmc_gibbs_run_device(bmc_ctx* ctx, int32_t n_chains, int64_t iters,
                          const uint64_t* seeds, void* d_samples_out, bmc_stats* stats);
 
+/* ---- simplex-constrained sampler ---------------------------------------------------
+ * Replaces gibbs_sampler_simplex, pybmc/inference_utils.py:59-144 (dispatched from
+ * pybmc/bmc.py:173-186): random-walk Metropolis on beta with the model weights
+ * beta Vt_hat + 1/n_models kept non-negative, Gibbs step for sigma2.  Uses the problem
+ * of bmc_set_problem (no prior call needed).  samples_out is [iters][k+1] rows
+ * [beta, sigma]; *accepted_out counts acceptances in the sampling phase (:135).
+ * rng_mode BMC_RNG_DEVICE: variates from the Philox generator keyed by seed.
+ * rng_mode BMC_RNG_REPLAY: xi [burn+iters][k] standard-normal proposal innovations
+ *   (proposal = current + S_hat*stepsize*xi), unif [n_unif] uniforms consumed ONLY by
+ *   proposals inside the simplex (:110,:132), g [burn+iters] Gamma((nu0+n)/2,1) variates.
+ * The reference's argument checks (:91-94) are the caller's (Python) job: burn >= 0,
+ * stepsize > 0 are re-checked here and give BMC_EINVAL. */
+int bmc_simplex_run(bmc_ctx* ctx, const double* Vt_hat, int32_t n_models, const double* S_hat,
+                    int64_t iters, int64_t burn, double stepsize, double nu0, double sigma20,
+                    int rng_mode, uint64_t seed, const double* xi, const double* unif,
+                    int64_t n_unif, const double* g, double* samples_out,
+                    int64_t* accepted_out, int64_t* unif_used_out, bmc_stats* stats);
+
 /* ---- posterior predictive -----------------------------------------------------
  * Replaces rndm_m_random_calculator, pybmc/sampling_utils.py:40-84 (callers
  * pybmc/bmc.py:227,323,367), and the interval test of coverage, :24-34.

@@ -161,7 +161,7 @@ def gibbs_port(y, X, iterations, prior_info):
 # gibbs_sampler_simplex
 # --------------------------------------------------------------------------
 def simplex_replay(y, X, Vt_hat, S_hat, iterations, prior_info, burn, stepsize,
-                   Z, U, G):
+                   Z, U, G, means_out=None):
     """inference_utils.py:78-144 with explicit streams.
 
     Z: (burn+iterations, K) standard normals of the proposal draw (:98,:121),
@@ -184,6 +184,8 @@ def simplex_replay(y, X, Vt_hat, S_hat, iterations, prior_info, burn, stepsize,
         raise ValueError("Stepsize must be positive.")
     out, acc, iu = [], 0, 0
     for t in range(burn + iterations):
+        if means_out is not None:
+            means_out.append(np.asarray(b_cur, dtype=float).copy())
         b_prop = mvn_draw_svd(np.asarray(b_cur, dtype=float), step_cov, Z[t])
         omegas = np.dot(b_prop, Vt_hat) + bias0                  # :99,:122
         if not np.any(omegas < 0):

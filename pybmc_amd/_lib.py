@@ -64,6 +64,9 @@ PROTOTYPES = {
                                 _D, C.POINTER(Stats)]),
     "bmc_gibbs_run_device": (C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_uint64), _P,
                                        C.POINTER(Stats)]),
+    "bmc_simplex_run": (C.c_int, [_P, _D, C.c_int32, _D, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                  C.c_double, C.c_int, C.c_uint64, _D, _D, C.c_int64, _D, _D,
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Stats)]),
     "bmc_predict": (C.c_int, [_P, _D, C.c_int64, C.c_int32, _D, C.c_int32, C.c_int32, _D, C.c_int,
                               C.c_uint64, _D, C.POINTER(C.c_int32), _D, C.c_int32, _D,
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _D, _D,
@@ -250,6 +253,35 @@ class Context:
             self._h, n_chains, iters, sd.ctypes.data_as(C.POINTER(C.c_uint64)), _P(out_ptr),
             C.byref(st)))
         return st.as_dict()
+
+    # -- simplex sampler --------------------------------------------------------------------
+    def simplex_run(self, Vt_hat, S_hat, iters, nu0, sigma20, burn, stepsize, seed=0, xi=None,
+                    unif=None, g=None, return_stats=False):
+        """Returns (samples (iters, k+1), accepted) [+ (uniforms used, stats)]."""
+        Vt_hat = np.ascontiguousarray(Vt_hat, dtype=np.float64)
+        S_hat = np.ascontiguousarray(S_hat, dtype=np.float64).reshape(-1)
+        if Vt_hat.ndim != 2 or Vt_hat.shape[0] != self.k or S_hat.shape[0] != self.k:
+            raise ValueError("Vt_hat must be (k, n_models) and S_hat (k,)")
+        out = np.empty((iters, self.k + 1))
+        acc, used, st = C.c_int64(), C.c_int64(), Stats()
+        if xi is not None:
+            tt = burn + iters
+            xi = np.ascontiguousarray(xi, dtype=np.float64).reshape(tt, self.k)
+            g = np.ascontiguousarray(g, dtype=np.float64).reshape(tt)
+            unif = np.ascontiguousarray(unif, dtype=np.float64).reshape(-1)
+            rc = self._lib.bmc_simplex_run(
+                self._h, _dptr(Vt_hat), Vt_hat.shape[1], _dptr(S_hat), iters, burn, stepsize, nu0,
+                sigma20, BMC_RNG_REPLAY, 0, _dptr(xi), _dptr(unif), unif.shape[0], _dptr(g),
+                _dptr(out), C.byref(acc), C.byref(used), C.byref(st))
+        else:
+            rc = self._lib.bmc_simplex_run(
+                self._h, _dptr(Vt_hat), Vt_hat.shape[1], _dptr(S_hat), iters, burn, stepsize, nu0,
+                sigma20, BMC_RNG_DEVICE, int(seed) & (2 ** 64 - 1), None, None, 0, None,
+                _dptr(out), C.byref(acc), C.byref(used), C.byref(st))
+        self._check(rc)
+        if return_stats:
+            return out, acc.value, used.value, st.as_dict()
+        return out, acc.value
 
     # -- posterior predictive --------------------------------------------------------------
     def predict(self, preds, theta, Vt_hat, seed=0, noise=None, q=(2.5, 50, 97.5), truth=None,

@@ -53,6 +53,7 @@ struct bmc_ctx {
     DevBuf xi, gam, uout, samples, gran, status, seeds, dbg, placement;
     // predictive buffers
     DevBuf pPreds, pTheta, pVt, pWt, pSig, pR, pNoise, pAux, pBands;
+    DevBuf sVt, sStep, sUnif, sOut, sCnt;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -433,7 +434,8 @@ void bmc_destroy(bmc_ctx* c) {
                       &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef, &c->ticket,
                       &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
                       &c->seeds, &c->dbg, &c->placement, &c->pPreds, &c->pTheta, &c->pVt,
-                      &c->pWt, &c->pSig, &c->pR, &c->pNoise, &c->pAux, &c->pBands})
+                      &c->pWt, &c->pSig, &c->pR, &c->pNoise, &c->pAux, &c->pBands, &c->sVt,
+                      &c->sStep, &c->sUnif, &c->sOut, &c->sCnt})
         release(*b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -719,6 +721,135 @@ int bmc_rng_fill(bmc_ctx* c, uint64_t seed, int64_t count_normal, double* normal
         HIPCHK(c, hipMemcpyAsync(gammas_out, c->gam.p, (size_t)count_gamma * 8,
                                  hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BMC_OK;
+}
+
+int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* S_hat,
+                    int64_t iters, int64_t burn, double stepsize, double nu0, double sigma20,
+                    int rng_mode, uint64_t seed, const double* xi, const double* unif,
+                    int64_t n_unif, const double* g, double* samples_out, int64_t* accepted_out,
+                    int64_t* unif_used_out, bmc_stats* stats) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_problem) return fail(c, BMC_ESTATE, "bmc_set_problem must be called first");
+    if (!Vt_hat || !S_hat || Km < 1) return fail(c, BMC_EINVAL, "Vt_hat/S_hat/n_models invalid");
+    if (burn < 0) return fail(c, BMC_EINVAL, "Burn-in iterations must be non-negative.");
+    if (!(stepsize > 0)) return fail(c, BMC_EINVAL, "Stepsize must be positive.");
+    if (iters < 0 || burn + iters >= 0xffffffffll) return fail(c, BMC_EINVAL, "bad iteration count");
+    if (iters > 0 && !samples_out) return fail(c, BMC_EINVAL, "samples_out must not be NULL");
+    if (rng_mode == BMC_RNG_REPLAY) {
+        if (!xi || !g || (n_unif > 0 && !unif) || n_unif < 0)
+            return fail(c, BMC_EINVAL, "xi, g and unif required in replay mode");
+    } else if (rng_mode == BMC_RNG_DEVICE) {
+        if (xi || g || unif) return fail(c, BMC_EINVAL, "xi/g/unif must be NULL in device RNG mode");
+    } else {
+        return fail(c, BMC_EINVAL, "rng_mode must be 0 or 1");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int K = c->k;
+    const size_t Tt = (size_t)(burn + iters);
+    int rc;
+    // -log_likelihood at beta = 0 (inference_utils.py:83-85) through the residual kernel
+    std::vector<double> zero(K, 0.0);
+    double rss0 = 0.0;
+    if ((rc = rss_on_raw(c, zero.data(), 1, &rss0))) return rc;
+    if ((rc = ensure(c, c->xi, Tt * K * 8)) || (rc = ensure(c, c->gam, Tt * 8)) ||
+        (rc = ensure(c, c->sVt, (size_t)K * Km * 8)) || (rc = ensure(c, c->sStep, (size_t)K * 8)) ||
+        (rc = ensure(c, c->sOut, (size_t)iters * (K + 1) * 8)) || (rc = ensure(c, c->sCnt, 64)) ||
+        (rc = ensure(c, c->status, 16)) || (rc = ensure(c, c->placement, 16)) ||
+        (rc = ensure(c, c->seeds, 16)))
+        return rc;
+    if (rng_mode == BMC_RNG_DEVICE) n_unif = (int64_t)Tt;
+    if ((rc = ensure(c, c->sUnif, (size_t)(n_unif > 0 ? n_unif : 1) * 8))) return rc;
+    std::vector<double> step(K);
+    for (int j = 0; j < K; ++j) step[j] = std::sqrt(S_hat[j] * S_hat[j] * stepsize * stepsize);  // :80
+    const Geometry geo = choose_geometry(c, 1);
+    const int gran_stride = ((2 * geo.G + 31) / 32) * 32;
+    if ((rc = ensure(c, c->gran, (size_t)3 * gran_stride * 8))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)3 * gran_stride * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->placement.p, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sCnt.p, 0, 64, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sVt.p, Vt_hat, (size_t)K * Km * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sStep.p, step.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (Tt > 0) {
+        if (rng_mode == BMC_RNG_DEVICE) {
+            HIPCHK(c, hipMemcpyAsync(c->seeds.p, &seed, 8, hipMemcpyHostToDevice, c->stream));
+            const double shape = (nu0 + (double)c->n) / 2.0;                       // :115
+            HIPCHK(c, launch_rng_fill((const uint64_t*)c->seeds.p, 1, (int64_t)Tt * K,
+                                      (double*)c->xi.p, shape, (int64_t)Tt, (double*)c->gam.p,
+                                      c->stream));
+            HIPCHK(c, launch_uniform_fill(seed, n_unif, (double*)c->sUnif.p, c->stream));
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->xi.p, xi, Tt * K * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->gam.p, g, Tt * 8, hipMemcpyHostToDevice, c->stream));
+            if (n_unif > 0)
+                HIPCHK(c, hipMemcpyAsync(c->sUnif.p, unif, (size_t)n_unif * 8, hipMemcpyHostToDevice,
+                                         c->stream));
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    SimplexArgs a;
+    a.P = panels_of(c, c->Xraw.p);
+    a.Vt = (const double*)c->sVt.p;
+    a.Km = Km;
+    a.vt_in_lds = (size_t)K * Km <= 4096;
+    a.step = (const double*)c->sStep.p;
+    a.nu0_s20 = nu0 * sigma20;
+    a.rss_init = rss0;
+    a.xi = (const double*)c->xi.p;
+    a.unif = (const double*)c->sUnif.p;
+    a.n_unif = n_unif;
+    a.gam = (const double*)c->gam.p;
+    a.out = (double*)c->sOut.p;
+    a.gran = (unsigned long long*)c->gran.p;
+    a.gran_stride = gran_stride;
+    a.status = (int32_t*)c->status.p;
+    a.placement = (int32_t*)c->placement.p;
+    a.counters = (long long*)c->sCnt.p;
+    a.iters = iters;
+    a.burn = burn;
+    a.G = geo.G;
+    a.waves = geo.waves;
+    a.mode = geo.mode;
+    a.reg_ppw = geo.ppw;
+    a.nslot = geo.nslot;
+    a.force_agent_scope = c->tune.force_agent_scope;
+    a.panels_per_group = geo.ppg;
+    if (a.vt_in_lds && simplex_lds_bytes(a) > LDS_LIMIT) a.vt_in_lds = 0;
+    if (simplex_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
+    if (Tt > 0) HIPCHK(c, launch_simplex(a, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    int32_t st = 0, place = 0;
+    long long cnt[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(&st, c->status.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&place, c->placement.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt, c->sCnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+    if (iters > 0)
+        HIPCHK(c, hipMemcpyAsync(samples_out, c->sOut.p, (size_t)iters * (K + 1) * 8,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (accepted_out) *accepted_out = cnt[0];
+    if (unif_used_out) *unif_used_out = cnt[1];
+    if (stats) {
+        float ms = 0;
+        std::memset(stats, 0, sizeof(*stats));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); stats->rng_ms = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); stats->loop_ms = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[2])); stats->total_ms = ms;
+        stats->iterations = burn + iters;
+        stats->n_chains = 1;
+        stats->launches = Tt > 0 ? 1 : 0;
+        stats->groups_per_chain = geo.G;
+        stats->waves_per_group = geo.waves;
+        stats->chains_per_pass = 1;
+        stats->residency = geo.mode + 1;
+        stats->xcd_local_chains = place ? 1 : 0;
+        stats->bytes_per_pass = ((int64_t)c->n * K + c->n) * (c->f32 ? 4 : 8);
+        stats->passes = cnt[1];
+    }
+    if (st == 1) return fail(c, BMC_ETIMEOUT, "persistent simplex kernel: bounded spin expired");
+    if (st == 2) return fail(c, BMC_EINVAL, "replay: fewer uniforms supplied than proposals inside the simplex");
     return BMC_OK;
 }
 

@@ -88,6 +88,6 @@ __host__ __device__ inline double u53_open0(uint32_t hi, uint32_t lo) {
 }
 
 enum : uint32_t { STREAM_NORMAL = 0x4e4f524du, STREAM_GAMMA = 0x47414d4du,
-                  STREAM_PRED_NORMAL = 0x50524544u, STREAM_PRED_PICK = 0x5049434bu };
+                  STREAM_PRED_NORMAL = 0x50524544u, STREAM_UNIFORM = 0x554e4946u };
 
 }  // namespace bmc

@@ -101,6 +101,32 @@ struct GibbsArgs {
     int32_t panels_per_group;  // max panels a group owns
     long long* dbg;         // diagnostic builds only (-DBMC_STAMPS); NULL otherwise
 };
+struct SimplexArgs {
+    Panels P;               // UN-rotated panels (the simplex sampler proposes beta itself)
+    const double* Vt;       // [k][Km]  Vt_hat
+    int32_t Km;
+    int32_t vt_in_lds;      // Vt_hat kept in LDS (k*Km <= 4096 doubles)
+    const double* step;     // [k]  S_hat * stepsize
+    double nu0_s20;
+    double rss_init;        // sum y^2 (beta = 0)
+    const double* xi;       // [burn+iters][k]
+    const double* unif;     // [n_unif]
+    int64_t n_unif;
+    const double* gam;      // [burn+iters]
+    double* out;            // [iters][k+1]
+    unsigned long long* gran;
+    int32_t gran_stride;
+    int32_t* status;        // 0 ok, 1 timeout, 2 uniforms exhausted
+    int32_t* placement;
+    long long* counters;    // [2] accepted (sampling phase), uniforms consumed
+    int64_t iters, burn;
+    int32_t G, waves, mode, reg_ppw, nslot, force_agent_scope, panels_per_group;
+};
+size_t simplex_lds_bytes(const SimplexArgs& a);
+hipError_t launch_simplex(const SimplexArgs& a, hipStream_t s);
+// uniforms in (0,1]: out[i] = u53(philox(counter = (i, STREAM_UNIFORM), key = seed))
+hipError_t launch_uniform_fill(uint64_t seed, int64_t n, double* out, hipStream_t s);
+
 size_t gibbs_lds_bytes(const GibbsArgs& a);
 int gibbs_reg_capacity(int k, int f32, int ppw);  // 1 if ppw panels of k columns fit in VGPRs
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s);

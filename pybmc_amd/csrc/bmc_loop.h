@@ -1,0 +1,297 @@
+// Building blocks shared by the persistent loop kernels (Gibbs and simplex samplers):
+// on-chip panel store, XCD placement check, group all-reduce of the partial rss.
+#pragma once
+#include "bmc_dev.h"
+#include "bmc_launch.h"
+
+namespace bmc {
+
+constexpr int MAX_KCH = 4;        // K <= 256 columns (64 per lane-chunk)
+constexpr int MAX_GRAN_REG = 8;   // 2*G <= 512 granules -> G <= 256
+constexpr unsigned long long SPIN_TIMEOUT_TICKS = 400000000ull;  // 4 s of s_memrealtime (100 MHz)
+
+enum { MODE_REG = 0, MODE_LDS = 1, MODE_STREAM = 2 };
+
+struct LdsPlan {
+    size_t u, red, ctl, aux, y, x, total;
+};
+
+// u: K doubles zero-padded to a multiple of 64 (MODE_REG reads KMAX of them);
+// aux: kernel-specific doubles (the simplex kernel keeps Vt_hat there when it fits).
+__host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bool lds_resident,
+                                            int aux_doubles = 0) {
+    LdsPlan L;
+    const size_t kp = (size_t)((K + 63) & ~63) * sizeof(double);
+    size_t o = 0;
+    L.u = o;   o += kp;
+    L.red = o; o += 16 * sizeof(double);
+    L.ctl = o; o += 8 * sizeof(double);
+    L.aux = o; o += (size_t)((aux_doubles + 1) & ~1) * sizeof(double);
+    L.y = o;
+    if (lds_resident) o += (size_t)ppg * RP * elem;
+    o = (o + 15) & ~(size_t)15;
+    L.x = o;
+    if (lds_resident) o += (size_t)ppg * K * RP * elem;
+    L.total = o;
+    return L;
+}
+
+// Diagnostic build only (-DBMC_STAMPS, scripts/dev_*): phase shares of one iteration as
+// seen by wave 0 of group 0 of chain 0.  The product build contains no stamp.
+#ifdef BMC_STAMPS
+#define STAMP(i)                                                                      \
+    do {                                                                              \
+        if (stamping) {                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+            unsigned long long now_;                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+            acc_[i] += now_ - last_;                                                  \
+            last_ = now_;                                                             \
+        }                                                                             \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+// ---- granule exchange ----------------------------------------------------------
+// LOCAL = the chain's groups were verified to share one XCD: the store stays in that
+// XCD's L2 (workgroup scope: global_store sc0) and the L1-bypassing agent-scope load
+// (global_load sc1) is served by the same L2.  Otherwise the store is agent scope
+// (sc1, write-through) and visible to every XCD.
+template <bool LOCAL>
+__device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned value) {
+    const gu64 w = ((gu64)epoch << 32) | (gu64)value;
+    if constexpr (LOCAL)
+        __hip_atomic_store(g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        __hip_atomic_store(g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Gather n2 granules of `epoch`; returns false when the bounded spin expired.
+__device__ __forceinline__ bool granule_gather(const gu64* gp, int n2, unsigned epoch, int lane,
+                                               gu64 (&x)[MAX_GRAN_REG]) {
+    unsigned long long t_start = 0;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < MAX_GRAN_REG; ++r) {
+            x[r] = 0;
+            if (r * 64 < n2) {
+                const int idx = r * 64 + lane;
+                if (idx < n2) {
+                    x[r] = granule_load(gp + idx);
+                    ok = ok && ((unsigned)(x[r] >> 32) == epoch);
+                }
+            }
+        }
+        if (__all(ok)) return true;
+        if ((spins & 0xff) == 0xff) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_start == 0) t_start = now;
+            else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
+        }
+    }
+}
+
+// even lane 2g' holds the high word of group g', odd lane the low word -> sum over g'
+__device__ __forceinline__ double granule_sum(const gu64 (&x)[MAX_GRAN_REG], int n2, int lane) {
+    double part = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAX_GRAN_REG; ++r) {
+        if (r * 64 < n2) {
+            const int w = (int)(unsigned)x[r];
+            const int other = __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true);
+            const double d = __hiloint2double(w, other);
+            part += ((lane & 1) == 0 && r * 64 + lane < n2) ? d : 0.0;
+        }
+    }
+    return wave_sum(part);
+}
+
+// Publish this group's XCC id, gather the chain's G ids (agent scope, always valid) and
+// decide: 1 = all groups on one XCD.  Run by wave 0; returns -1 when the spin expired.
+__device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, int lane) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (lane == 0)
+        __hip_atomic_store(xcc_words + g, (gu64)(xcc + 1), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true;
+    unsigned long long t_start = 0;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        same = true;
+        for (int b = 0; b < G; b += 64) {
+            const int idx = b + lane;
+            gu64 w = xcc + 1;
+            if (idx < G) w = __hip_atomic_load(xcc_words + idx, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (w != 0);
+            same = same && (w == (gu64)(xcc + 1));
+        }
+        if (__all(ok)) break;
+        if ((spins & 0xff) == 0xff) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_start == 0) t_start = now;
+            else if (now - t_start > SPIN_TIMEOUT_TICKS) return -1;
+        }
+    }
+    return __all(same) ? 1 : 0;
+}
+
+// ---- partial rss of one panel, data in memory (LDS or global) ---------------------
+template <typename T, int VEC>
+__device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* __restrict__ yp,
+                                            const double* __restrict__ u, int K) {
+    constexpr int RP = 64 * VEC;
+    double a0[VEC], a1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { a0[v] = (double)yp[v]; a1[v] = 0.0; }
+    int j = 0;
+#pragma unroll 4
+    for (; j + 1 < K; j += 2) {
+        const double u0 = u[j], u1 = u[j + 1];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            a0[v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[v]);
+            a1[v] = fma(-(double)xp[(size_t)(j + 1) * RP + v], u1, a1[v]);
+        }
+    }
+    if (j < K) {
+        const double u0 = u[j];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a0[v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[v]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const double r = a0[v] + a1[v];
+        s = fma(r, r, s);
+    }
+    return s;
+}
+
+// ---- the group's row panels, pinned on chip (or streamed) ---------------------------
+// Group g owns panels g, g+G, ...; wave w of the group handles local panels w, w+nw, ...
+template <typename T, int VEC, int MODE, int KMAX, int PPW>
+struct PanelStore {
+    static constexpr int RP = 64 * VEC;
+    T xr[PPW > 0 ? PPW : 1][KMAX > 0 ? KMAX : 1];
+    T yr[PPW > 0 ? PPW : 1];
+    const T* Xg;
+    const T* yg;
+    T* Xs;
+    T* ys;
+    int K, G, g, npl, nw, wave, lane;
+
+    __device__ __forceinline__ void init(const Panels& P, int G_, int g_, T* Xs_, T* ys_) {
+        static_assert(MODE != MODE_REG || VEC == 1, "register mode keeps one row per lane");
+        Xg = reinterpret_cast<const T*>(P.X);
+        yg = reinterpret_cast<const T*>(P.y);
+        Xs = Xs_;
+        ys = ys_;
+        K = P.k;
+        G = G_;
+        g = g_;
+        const int NP = P.npanels;
+        npl = g < NP ? (NP - g + G - 1) / G : 0;
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        nw = blockDim.x >> 6;
+        if constexpr (MODE == MODE_REG) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int q = wave + i * nw;
+                const bool have = q < npl;
+                const int64_t p = g + (int64_t)q * G;
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j)
+                    xr[i][j] = (have && j < K) ? Xg[(p * K + j) * RP + lane] : (T)0;
+                yr[i] = have ? yg[p * RP + lane] : (T)0;
+            }
+        } else if constexpr (MODE == MODE_LDS) {
+            constexpr int EPV = 16 / (int)sizeof(T);
+            const int vec_per_panel = K * RP / EPV;
+            for (int q = 0; q < npl; ++q) {
+                const int64_t p = g + (int64_t)q * G;
+                const uint4* src = reinterpret_cast<const uint4*>(Xg + p * (int64_t)K * RP);
+                uint4* dst = reinterpret_cast<uint4*>(Xs + (size_t)q * K * RP);
+                for (int e = tid; e < vec_per_panel; e += blockDim.x) dst[e] = src[e];
+                for (int e = tid; e < RP; e += blockDim.x) ys[q * RP + e] = yg[p * RP + e];
+            }
+        }
+    }
+
+    // this lane's share of sum (y - X u)^2 over the wave's panels; u_lds zero-padded to 64
+    __device__ __forceinline__ double partial_rss(const double* __restrict__ u_lds) const {
+        double s = 0.0;
+        if constexpr (MODE == MODE_REG) {
+            double acc[PPW][4];
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                acc[i][0] = (double)yr[i];
+                acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < KMAX; j += 4) {
+                const double u0 = u_lds[j], u1 = u_lds[j + 1], u2 = u_lds[j + 2], u3 = u_lds[j + 3];
+#pragma unroll
+                for (int i = 0; i < PPW; ++i) {
+                    acc[i][0] = fma(-(double)xr[i][j], u0, acc[i][0]);
+                    acc[i][1] = fma(-(double)xr[i][j + 1], u1, acc[i][1]);
+                    acc[i][2] = fma(-(double)xr[i][j + 2], u2, acc[i][2]);
+                    acc[i][3] = fma(-(double)xr[i][j + 3], u3, acc[i][3]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const double r = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
+                s = fma(r, r, s);
+            }
+        } else {
+            for (int q = wave; q < npl; q += nw) {
+                if constexpr (MODE == MODE_LDS) {
+                    s += panel_rss<T, VEC>(Xs + (size_t)q * K * RP + lane * VEC,
+                                           ys + q * RP + lane * VEC, u_lds, K);
+                } else {
+                    const int64_t p = g + (int64_t)q * G;
+                    s += panel_rss<T, VEC>(Xg + p * (int64_t)K * RP + lane * VEC,
+                                           yg + p * RP + lane * VEC, u_lds, K);
+                }
+            }
+        }
+        return s;
+    }
+};
+
+// ---- all-reduce of the lane partials over the chain's groups -----------------------------
+// Every wave calls it (it contains the group barrier).  In wave 0 the return value is the
+// chain-wide sum (identical bits in every group); `ok` is false when the spin expired.
+// Other waves get an unspecified value.  Order of summation is fixed: DPP butterfly inside a
+// wave, waves in index order, groups in index order.
+__device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
+                                                  int wave, int nw, int lane, unsigned epoch,
+                                                  bool local, bool& ok) {
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    ok = true;
+    if (wave != 0) return 0.0;
+    s = red[0];
+    for (int w = 1; w < nw; ++w) s += red[w];
+    if (lane == 0) {
+        if (local) {
+            granule_put<true>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));
+            granule_put<true>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(s));
+        } else {
+            granule_put<false>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));
+            granule_put<false>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(s));
+        }
+    }
+    gu64 x[MAX_GRAN_REG];
+    ok = granule_gather(gp, 2 * G, epoch, lane, x);
+    return ok ? granule_sum(x, 2 * G, lane) : 0.0;
+}
+
+}  // namespace bmc

@@ -36,147 +36,13 @@
 // wrong placement guess costs speed, never correctness.
 // All spins are bounded (wall clock); on expiry the chain's status word is set and
 // every group leaves the loop.
-#include "bmc_dev.h"
-#include "bmc_launch.h"
+#include "bmc_loop.h"
 
 namespace bmc {
-
-constexpr int MAX_KCH = 4;        // K <= 256 columns (64 per lane-chunk)
-constexpr int MAX_GRAN_REG = 8;   // 2*G <= 512 granules -> G <= 256
-constexpr unsigned long long SPIN_TIMEOUT_TICKS = 400000000ull;  // 4 s of s_memrealtime (100 MHz)
-
-enum { MODE_REG = 0, MODE_LDS = 1, MODE_STREAM = 2 };
-
-struct LdsPlan {
-    size_t u, red, ctl, y, x, total;
-};
-
-__host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bool lds_resident) {
-    LdsPlan L;
-    const size_t kp = (size_t)((K + 63) & ~63) * sizeof(double);  // zero-padded to 64 (MODE_REG reads KMAX)
-    size_t o = 0;
-    L.u = o;   o += kp;
-    L.red = o; o += 16 * sizeof(double);
-    L.ctl = o; o += 4 * sizeof(double);
-    L.y = o;
-    if (lds_resident) o += (size_t)ppg * RP * elem;
-    o = (o + 15) & ~(size_t)15;
-    L.x = o;
-    if (lds_resident) o += (size_t)ppg * K * RP * elem;
-    L.total = o;
-    return L;
-}
-
-// Diagnostic build only (-DBMC_STAMPS, scripts/dev_*): phase shares of one iteration as
-// seen by wave 0 of group 0 of chain 0.  The product build contains no stamp.
-#ifdef BMC_STAMPS
-#define STAMP(i)                                                                      \
-    do {                                                                              \
-        if (stamping) {                                                               \
-            __builtin_amdgcn_sched_barrier(0);                                        \
-            unsigned long long now_;                                                  \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
-            __builtin_amdgcn_sched_barrier(0);                                        \
-            acc_[i] += now_ - last_;                                                  \
-            last_ = now_;                                                             \
-        }                                                                             \
-    } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-
-// ---- granule exchange ----------------------------------------------------------
-// LOCAL = the chain's groups were verified to share one XCD: the store stays in that
-// XCD's L2 (workgroup scope: global_store sc0) and the L1-bypassing agent-scope load
-// (global_load sc1) is served by the same L2.  Otherwise the store is agent scope
-// (sc1, write-through) and visible to every XCD.
-template <bool LOCAL>
-__device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned value) {
-    const gu64 w = ((gu64)epoch << 32) | (gu64)value;
-    if constexpr (LOCAL)
-        __hip_atomic_store(g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-        __hip_atomic_store(g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Gather n2 granules of `epoch`; returns false when the bounded spin expired.
-__device__ __forceinline__ bool granule_gather(const gu64* gp, int n2, unsigned epoch, int lane,
-                                               gu64 (&x)[MAX_GRAN_REG]) {
-    unsigned long long t_start = 0;
-    for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int r = 0; r < MAX_GRAN_REG; ++r) {
-            x[r] = 0;
-            if (r * 64 < n2) {
-                const int idx = r * 64 + lane;
-                if (idx < n2) {
-                    x[r] = granule_load(gp + idx);
-                    ok = ok && ((unsigned)(x[r] >> 32) == epoch);
-                }
-            }
-        }
-        if (__all(ok)) return true;
-        if ((spins & 0xff) == 0xff) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t_start == 0) t_start = now;
-            else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
-        }
-    }
-}
-
-// even lane 2g' holds the high word of group g', odd lane the low word -> sum over g'
-__device__ __forceinline__ double granule_sum(const gu64 (&x)[MAX_GRAN_REG], int n2, int lane) {
-    double part = 0.0;
-#pragma unroll
-    for (int r = 0; r < MAX_GRAN_REG; ++r) {
-        if (r * 64 < n2) {
-            const int w = (int)(unsigned)x[r];
-            const int other = __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true);
-            const double d = __hiloint2double(w, other);
-            part += ((lane & 1) == 0 && r * 64 + lane < n2) ? d : 0.0;
-        }
-    }
-    return wave_sum(part);
-}
-
-// ---- partial rss of one panel, data in memory (LDS or global) ---------------------
-template <typename T, int VEC>
-__device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* __restrict__ yp,
-                                            const double* __restrict__ u, int K) {
-    constexpr int RP = 64 * VEC;
-    double a0[VEC], a1[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) { a0[v] = (double)yp[v]; a1[v] = 0.0; }
-    int j = 0;
-#pragma unroll 4
-    for (; j + 1 < K; j += 2) {
-        const double u0 = u[j], u1 = u[j + 1];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            a0[v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[v]);
-            a1[v] = fma(-(double)xp[(size_t)(j + 1) * RP + v], u1, a1[v]);
-        }
-    }
-    if (j < K) {
-        const double u0 = u[j];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) a0[v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[v]);
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        const double r = a0[v] + a1[v];
-        s = fma(r, r, s);
-    }
-    return s;
-}
 
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
-    constexpr bool LDSRES = MODE == MODE_LDS;
-    static_assert(MODE != MODE_REG || VEC == 1, "register mode keeps one row per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = a.P.k;
     const int C = a.n_chains, G = a.G;
@@ -189,80 +55,25 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
     const int nw = blockDim.x >> 6;
     const int64_t T_it = a.iters;
 
-    const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, LDSRES);
+    const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, MODE == MODE_LDS);
     double* u_lds = reinterpret_cast<double*>(smem + L.u);
-    double* red = reinterpret_cast<double*>(smem + L.red);  // per-wave partials (group publish)
+    double* red = reinterpret_cast<double*>(smem + L.red);  // per-wave partials
     double* ctl = reinterpret_cast<double*>(smem + L.ctl);  // [0] sp, [1] abort, [2] local, [3] g
-    T* ys = reinterpret_cast<T*>(smem + L.y);
-    T* Xs = reinterpret_cast<T*>(smem + L.x);
-
-    const int NP = a.P.npanels;
-    const int npl = g < NP ? (NP - g + G - 1) / G : 0;  // panels owned by this group
-    const T* Xg = reinterpret_cast<const T*>(a.P.X);
-    const T* yg = reinterpret_cast<const T*>(a.P.y);
 
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad; j += blockDim.x) u_lds[j] = 0.0;
     if (tid == 0) { ctl[0] = a.sigma2_init; ctl[1] = 0.0; ctl[2] = 0.0; ctl[3] = 1.0; }
 
-    // ---- pin the group's panels on chip -------------------------------------------
-    T xr[PPW > 0 ? PPW : 1][KMAX > 0 ? KMAX : 1];
-    T yr[PPW > 0 ? PPW : 1];
-    if constexpr (MODE == MODE_REG) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int q = wave + i * nw;
-            const bool have = q < npl;
-            const int64_t p = g + (int64_t)q * G;
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j)
-                xr[i][j] = (have && j < K) ? Xg[(p * K + j) * RP + lane] : (T)0;
-            yr[i] = have ? yg[p * RP + lane] : (T)0;
-        }
-    } else if constexpr (MODE == MODE_LDS) {
-        constexpr int EPV = 16 / (int)sizeof(T);
-        const int vec_per_panel = K * RP / EPV;
-        for (int q = 0; q < npl; ++q) {
-            const int64_t p = g + (int64_t)q * G;
-            const uint4* src = reinterpret_cast<const uint4*>(Xg + p * (int64_t)K * RP);
-            uint4* dst = reinterpret_cast<uint4*>(Xs + (size_t)q * K * RP);
-            for (int e = tid; e < vec_per_panel; e += blockDim.x) dst[e] = src[e];
-            for (int e = tid; e < RP; e += blockDim.x) ys[q * RP + e] = yg[p * RP + e];
-        }
-    }
+    PanelStore<T, VEC, MODE, KMAX, PPW> store;
+    store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y));
 
     // ---- where do this chain's groups really run? -------------------------------------
-    gu64* gr = a.gran + (size_t)chain * (2 * a.gran_stride + a.gran_stride);
-    gu64* xcc_words = gr + 2 * a.gran_stride;  // [G] one word per group: 1 + XCC id
+    gu64* gr = a.gran + (size_t)chain * 3 * a.gran_stride;
     if (wave == 0) {
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
-        if (lane == 0)
-            __hip_atomic_store(xcc_words + g, (gu64)(xcc + 1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        bool same = true, expired = false;
-        unsigned long long t_start = 0;
-        for (unsigned spins = 0;; ++spins) {
-            bool ok = true;
-            same = true;
-            for (int b = 0; b < G; b += 64) {
-                const int idx = b + lane;
-                gu64 w = xcc + 1;
-                if (idx < G) w = __hip_atomic_load(xcc_words + idx, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && (w != 0);
-                same = same && (w == (gu64)(xcc + 1));
-            }
-            if (__all(ok)) break;
-            if ((spins & 0xff) == 0xff) {
-                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                if (t_start == 0) t_start = now;
-                else if (now - t_start > SPIN_TIMEOUT_TICKS) { expired = true; break; }
-            }
-        }
-        const bool all_same = __all(same);
+        const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane);
         if (lane == 0) {
-            if (expired) { ctl[1] = 1.0; a.status[chain] = 1; }
-            ctl[2] = (!expired && all_same && !a.force_agent_scope) ? 1.0 : 0.0;
+            if (place < 0) { ctl[1] = 1.0; a.status[chain] = 1; }
+            ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
         }
     }
     __syncthreads();
@@ -273,7 +84,6 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
     const double* gam = a.gam + (int64_t)chain * T_it;
     double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
     const bool recorder = (g == 0) && (wave == nw - 1);
-    const int n2 = 2 * G;
 
     // sigma2 = sp_eff / g_eff; starts at the OLS value (inference_utils.py:37)
     double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
@@ -290,9 +100,6 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
         }
         if (T_it > 0) gam_next = gam[0];
     }
-    // Exchange participants are the G groups: the waves of a group combine through LDS
-    // first.  (Measured: letting every wave publish its own partial removes a barrier
-    // but makes the gather 1.7x longer at 160 participants -- a net loss.)
 
 #ifdef BMC_STAMPS
     const bool stamping = a.dbg != nullptr && blockIdx.x == 0 && wave == 0;
@@ -315,7 +122,7 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
             }
         }
         STAMP(0);
-        __syncthreads();  // B1: u (and the previous s2 / abort word) visible to all waves
+        __syncthreads();  // B1: u (and the previous sp, g / abort word) visible to all waves
         if (ctl[1] != 0.0) break;
         STAMP(1);
 
@@ -339,63 +146,13 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
             g_rec = ctl[3];
         }
 
-        // ---- partial rss over this group's panels ---------------------------------
-        double s = 0.0;
-        if constexpr (MODE == MODE_REG) {
-            double acc[PPW][4];
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                acc[i][0] = (double)yr[i];
-                acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < KMAX; j += 4) {
-                // four broadcast reads of u (zero beyond K), shared by the wave's panels
-                const double u0 = u_lds[j], u1 = u_lds[j + 1], u2 = u_lds[j + 2], u3 = u_lds[j + 3];
-#pragma unroll
-                for (int i = 0; i < PPW; ++i) {
-                    acc[i][0] = fma(-(double)xr[i][j], u0, acc[i][0]);
-                    acc[i][1] = fma(-(double)xr[i][j + 1], u1, acc[i][1]);
-                    acc[i][2] = fma(-(double)xr[i][j + 2], u2, acc[i][2]);
-                    acc[i][3] = fma(-(double)xr[i][j + 3], u3, acc[i][3]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const double r = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
-                s = fma(r, r, s);
-            }
-        } else {
-            for (int q = wave; q < npl; q += nw) {
-                if constexpr (MODE == MODE_LDS) {
-                    s += panel_rss<T, VEC>(Xs + (size_t)q * K * RP + lane * VEC,
-                                           ys + q * RP + lane * VEC, u_lds, K);
-                } else {
-                    const int64_t p = g + (int64_t)q * G;
-                    s += panel_rss<T, VEC>(Xg + p * (int64_t)K * RP + lane * VEC,
-                                           yg + p * RP + lane * VEC, u_lds, K);
-                }
-            }
-        }
+        // ---- partial rss over this group's panels, then over the chain's groups ---------
+        const double part = store.partial_rss(u_lds);
         STAMP(2);
-        s = wave_sum(s);
-        gu64* gp = gr + (size_t)(t & 1) * a.gran_stride;
-        if (lane == 0) red[wave] = s;
-        __syncthreads();  // B2: group-level combine in fixed wave order, wave 0 publishes
-        if (wave == 0) {
-            s = red[0];
-            for (int w = 1; w < nw; ++w) s += red[w];
-            if (lane == 0) {
-                if (local) {
-                    granule_put<true>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));
-                    granule_put<true>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(s));
-                } else {
-                    granule_put<false>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));
-                    granule_put<false>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(s));
-                }
-            }
-        }
-        STAMP(3);
+        bool got;
+        const double rss = group_allreduce(part, red, gr + (size_t)(t & 1) * a.gran_stride, G, g,
+                                           wave, nw, lane, epoch, local, got);
+        STAMP(5);
         if (recorder) {
             // row t = [u_t, .]; sigma of the PREVIOUS row (its sp, g were final at B1)
 #pragma unroll
@@ -405,16 +162,10 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
             }
             if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
         }
-        STAMP(4);
-
         if (wave == 0) {
-            gu64 x[MAX_GRAN_REG];
-            const bool got = granule_gather(gp, n2, epoch, lane, x);
-            STAMP(5);
             if (!got) {
                 if (lane == 0) { ctl[1] = 1.0; a.status[chain] = 1; }
             } else {
-                const double rss = granule_sum(x, n2, lane);
                 // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
                 const double scale_post = (a.nu0_s20 + rss) * 0.5;
                 const bool floor_hit = scale_post < 1e-6 * gam_t;
@@ -435,12 +186,179 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
         uout[(T_it - 1) * (K + 1) + K] = sqrt(ctl[0] / ctl[3]);
 }
 
+// ======================================================================================
+// Simplex-constrained sampler (reference pybmc/inference_utils.py:78-144): random-walk
+// Metropolis on beta with the weights beta Vt_hat + 1/Km kept on the simplex, Gibbs step
+// for sigma2.  Same machinery: the proposal's rss is the group all-reduce above.  A
+// proposal outside the simplex skips the residual pass AND consumes no uniform (:102,
+// :124): every group evaluates the simplex test on identical bits, so all skip together;
+// the exchange epoch counts exchanges, not iterations.
+// ======================================================================================
+template <typename T, int VEC, int MODE, int KMAX, int PPW>
+__global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void simplex_loop_kernel(SimplexArgs a) {
+    constexpr int RP = 64 * VEC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = a.P.k, Km = a.Km, G = a.G;
+    const int chain = blockIdx.x % a.nslot;
+    const int g = blockIdx.x / a.nslot;
+    if (chain >= 1) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = blockDim.x >> 6;
+    const int64_t T_tot = a.burn + a.iters;
+
+    const int aux_n = a.vt_in_lds ? K * Km : 0;
+    const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, MODE == MODE_LDS, aux_n);
+    double* u_lds = reinterpret_cast<double*>(smem + L.u);
+    double* red = reinterpret_cast<double*>(smem + L.red);
+    double* ctl = reinterpret_cast<double*>(smem + L.ctl);  // [1] abort, [2] local, [4] inside
+    double* vt_lds = reinterpret_cast<double*>(smem + L.aux);
+    const double* vt = a.vt_in_lds ? vt_lds : a.Vt;
+
+    const int kpad = (K + 63) & ~63;
+    for (int j = tid; j < kpad; j += blockDim.x) u_lds[j] = 0.0;
+    if (a.vt_in_lds)
+        for (int e = tid; e < K * Km; e += blockDim.x) vt_lds[e] = a.Vt[e];
+    if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; ctl[4] = 0.0; }
+
+    PanelStore<T, VEC, MODE, KMAX, PPW> store;
+    store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y));
+
+    gu64* gr = a.gran;
+    if (wave == 0) {
+        const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane);
+        if (lane == 0) {
+            if (place < 0) { ctl[1] = 1.0; a.status[0] = 1; }
+            ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    const bool local = ctl[2] != 0.0;
+    if (g == 0 && tid == 0) a.placement[0] = local ? 1 : 0;
+
+    double b_cur[MAX_KCH], b_prop[MAX_KCH], step_r[MAX_KCH], xi_next[MAX_KCH];
+    double rss_cur = a.rss_init;                       // -log_likelihood_current (:85)
+    double s2 = a.rss_init / (double)a.P.n;            // :86
+    double gam_next = 0.0, unif_next = 0.5;
+    int64_t iu = 0, accepted = 0;
+    unsigned nex = 0;                                   // exchanges so far
+    const double w0 = 1.0 / (double)Km;
+    if (wave == 0) {
+#pragma unroll
+        for (int ch = 0; ch < MAX_KCH; ++ch) {
+            const int j = ch * 64 + lane;
+            b_cur[ch] = 0.0;                            // :82
+            b_prop[ch] = 0.0;
+            step_r[ch] = j < K ? a.step[j] : 0.0;
+            xi_next[ch] = (j < K && T_tot > 0) ? a.xi[j] : 0.0;
+        }
+        if (T_tot > 0) gam_next = a.gam[0];
+        if (a.n_unif > 0) unif_next = a.unif[0];
+    }
+
+    for (int64_t t = 0; t < T_tot; ++t) {
+        if (wave == 0) {
+            // proposal b_cur + diag(S_hat stepsize) xi  (:98,:121: mvn with a diagonal cov)
+#pragma unroll
+            for (int ch = 0; ch < MAX_KCH; ++ch) {
+                const int j = ch * 64 + lane;
+                if (ch * 64 < K && j < K) {
+                    b_prop[ch] = fma(step_r[ch], xi_next[ch], b_cur[ch]);
+                    u_lds[j] = b_prop[ch];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // omegas = b_prop Vt_hat + 1/Km >= 0 ?                          (:99-102)
+            bool neg = false;
+            for (int m = lane; m < Km; m += 64) {
+                double o0 = w0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+                int j = 0;
+                for (; j + 3 < K; j += 4) {
+                    o0 = fma(u_lds[j], vt[(size_t)j * Km + m], o0);
+                    o1 = fma(u_lds[j + 1], vt[(size_t)(j + 1) * Km + m], o1);
+                    o2 = fma(u_lds[j + 2], vt[(size_t)(j + 2) * Km + m], o2);
+                    o3 = fma(u_lds[j + 3], vt[(size_t)(j + 3) * Km + m], o3);
+                }
+                for (; j < K; ++j) o0 = fma(u_lds[j], vt[(size_t)j * Km + m], o0);
+                neg = neg || ((o0 + o1) + (o2 + o3) < 0.0);
+            }
+            const bool inside = !__any(neg);
+            if (lane == 0) ctl[4] = inside ? 1.0 : 0.0;
+        }
+        __syncthreads();  // B1
+        if (ctl[1] != 0.0) break;
+        const bool inside = ctl[4] != 0.0;
+
+        const double gam_t = gam_next;
+        if (wave == 0 && t + 1 < T_tot) {
+#pragma unroll
+            for (int ch = 0; ch < MAX_KCH; ++ch) {
+                const int j = ch * 64 + lane;
+                if (ch * 64 < K && j < K) xi_next[ch] = a.xi[(t + 1) * K + j];
+            }
+            gam_next = a.gam[t + 1];
+        }
+
+        if (inside) {
+            const double part = store.partial_rss(u_lds);
+            bool got;
+            const double rss_prop = group_allreduce(part, red, gr + (size_t)(nex & 1) * a.gran_stride,
+                                                    G, g, wave, nw, lane, nex + 1, local, got);
+            ++nex;
+            if (wave == 0) {
+                if (!got || iu >= a.n_unif) {
+                    if (lane == 0) { ctl[1] = 1.0; a.status[0] = got ? 2 : 1; }
+                } else {
+                    // min(1, exp((ll_prop - ll_cur) / sigma2)), ll = -rss     (:106-109)
+                    const double ratio = exp((rss_cur - rss_prop) / s2);
+                    const double p_acc = ratio < 1.0 ? ratio : 1.0;
+                    const double uu = unif_next;
+                    ++iu;
+                    if (iu < a.n_unif) unif_next = a.unif[iu];
+                    if (uu < p_acc) {                                          // :110-112
+#pragma unroll
+                        for (int ch = 0; ch < MAX_KCH; ++ch) b_cur[ch] = b_prop[ch];
+                        rss_cur = rss_prop;
+                        if (t >= a.burn) ++accepted;
+                    }
+                }
+            }
+        }
+        if (wave == 0) {
+            // sigma2 = 1 / Gamma(shape, 1/scale_post), no floor on this path      (:115-117)
+            const double scale_post = (a.nu0_s20 + rss_cur) * 0.5;
+            s2 = scale_post / gam_t;
+            if (g == 0 && t >= a.burn) {
+                double* row = a.out + (t - a.burn) * (K + 1);
+#pragma unroll
+                for (int ch = 0; ch < MAX_KCH; ++ch) {
+                    const int j = ch * 64 + lane;
+                    if (ch * 64 < K && j < K) row[j] = b_cur[ch];
+                }
+                if (lane == 0) row[K] = sqrt(s2);
+            }
+        }
+    }
+    if (g == 0 && tid == 0) {
+        a.counters[0] = accepted;
+        a.counters[1] = iu;
+    }
+}
+
 size_t gibbs_lds_bytes(const GibbsArgs& a) {
     return lds_plan(a.P.k, a.P.f32 ? 4 : 8, 64 * a.P.vec, a.panels_per_group, a.mode == MODE_LDS).total;
 }
+size_t simplex_lds_bytes(const SimplexArgs& a) {
+    return lds_plan(a.P.k, a.P.f32 ? 4 : 8, 64 * a.P.vec, a.panels_per_group, a.mode == MODE_LDS,
+                    a.vt_in_lds ? a.P.k * a.Km : 0).total;
+}
+
+// ---- dispatch over <T, VEC, MODE, KMAX, PPW>: one table for both kernels ----------------
+struct GibbsTag {};
+struct SimplexTag {};
 
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
-static hipError_t gibbs_launch_one(const GibbsArgs& a, hipStream_t s) {
+static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
     hipError_t e = hipFuncSetAttribute((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -449,35 +367,45 @@ static hipError_t gibbs_launch_one(const GibbsArgs& a, hipStream_t s) {
                        dim3(64 * a.waves), lds, s, a);
     return hipGetLastError();
 }
+template <typename T, int VEC, int MODE, int KMAX, int PPW>
+static hipError_t launch_one(SimplexTag, const SimplexArgs& a, hipStream_t s) {
+    const size_t lds = simplex_lds_bytes(a);
+    hipError_t e = hipFuncSetAttribute((const void*)simplex_loop_kernel<T, VEC, MODE, KMAX, PPW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((simplex_loop_kernel<T, VEC, MODE, KMAX, PPW>), dim3(a.nslot * a.G),
+                       dim3(64 * a.waves), lds, s, a);
+    return hipGetLastError();
+}
 
-template <typename T, int KMAX>
-static hipError_t gibbs_launch_reg(const GibbsArgs& a, hipStream_t s) {
+template <typename Tag, typename Args, typename T, int KMAX>
+static hipError_t launch_reg(const Args& a, hipStream_t s) {
     switch (a.reg_ppw) {
         // panel data is held as f64: PPW * KMAX * 2 <= 128 VGPRs keeps the kernel spill-free
-        case 1: return gibbs_launch_one<T, 1, MODE_REG, KMAX, 1>(a, s);
+        case 1: return launch_one<T, 1, MODE_REG, KMAX, 1>(Tag{}, a, s);
         case 2:
-            if constexpr (KMAX <= 32) return gibbs_launch_one<T, 1, MODE_REG, KMAX, 2>(a, s);
+            if constexpr (KMAX <= 32) return launch_one<T, 1, MODE_REG, KMAX, 2>(Tag{}, a, s);
             break;
         case 4:
-            if constexpr (KMAX <= 16) return gibbs_launch_one<T, 1, MODE_REG, KMAX, 4>(a, s);
+            if constexpr (KMAX <= 16) return launch_one<T, 1, MODE_REG, KMAX, 4>(Tag{}, a, s);
             break;
     }
     return hipErrorInvalidValue;
 }
 
-template <typename T>
-static hipError_t gibbs_launch_t(const GibbsArgs& a, hipStream_t s) {
+template <typename Tag, typename Args, typename T>
+static hipError_t launch_t(const Args& a, hipStream_t s) {
     if (a.mode == MODE_REG) {
         if (a.P.vec != 1 || a.waves > 8) return hipErrorInvalidValue;
-        if (a.P.k <= 8) return gibbs_launch_reg<T, 8>(a, s);
-        if (a.P.k <= 16) return gibbs_launch_reg<T, 16>(a, s);
-        if (a.P.k <= 32) return gibbs_launch_reg<T, 32>(a, s);
-        if (a.P.k <= 64) return gibbs_launch_reg<T, 64>(a, s);
+        if (a.P.k <= 8) return launch_reg<Tag, Args, T, 8>(a, s);
+        if (a.P.k <= 16) return launch_reg<Tag, Args, T, 16>(a, s);
+        if (a.P.k <= 32) return launch_reg<Tag, Args, T, 32>(a, s);
+        if (a.P.k <= 64) return launch_reg<Tag, Args, T, 64>(a, s);
         return hipErrorInvalidValue;
     }
 #define BMC_MEM(V)                                                                   \
-    (a.mode == MODE_LDS ? gibbs_launch_one<T, V, MODE_LDS, 0, 0>(a, s)               \
-                        : gibbs_launch_one<T, V, MODE_STREAM, 0, 0>(a, s))
+    (a.mode == MODE_LDS ? launch_one<T, V, MODE_LDS, 0, 0>(Tag{}, a, s)               \
+                        : launch_one<T, V, MODE_STREAM, 0, 0>(Tag{}, a, s))
     switch (a.P.vec) {
         case 1: return BMC_MEM(1);
         case 2: return BMC_MEM(2);
@@ -497,11 +425,22 @@ int gibbs_reg_capacity(int k, int f32, int ppw) {
     return ppw * kmax * 2 <= 128 ? 1 : 0;
 }
 
+template <typename Args>
+static bool geometry_ok(const Args& a) {
+    return a.P.k <= 64 * MAX_KCH && a.G <= 32 * MAX_GRAN_REG && a.G >= 1 && a.waves >= 1 &&
+           a.waves <= 16 && a.nslot >= 1 && a.nslot <= 256;
+}
+
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
-    if (a.P.k > 64 * MAX_KCH || a.G > 32 * MAX_GRAN_REG || a.G < 1 || a.waves < 1 ||
-        a.waves > 16 || a.n_chains < 1 || a.n_chains > a.nslot || a.nslot > 256)
-        return hipErrorInvalidValue;
-    return a.P.f32 ? gibbs_launch_t<float>(a, s) : gibbs_launch_t<double>(a, s);
+    if (!geometry_ok(a) || a.n_chains < 1 || a.n_chains > a.nslot) return hipErrorInvalidValue;
+    return a.P.f32 ? launch_t<GibbsTag, GibbsArgs, float>(a, s)
+                   : launch_t<GibbsTag, GibbsArgs, double>(a, s);
+}
+
+hipError_t launch_simplex(const SimplexArgs& a, hipStream_t s) {
+    if (!geometry_ok(a) || a.Km < 1) return hipErrorInvalidValue;
+    return a.P.f32 ? launch_t<SimplexTag, SimplexArgs, float>(a, s)
+                   : launch_t<SimplexTag, SimplexArgs, double>(a, s);
 }
 
 }  // namespace bmc

@@ -540,6 +540,26 @@ hipError_t launch_rng_fill(const uint64_t* seeds_dev, int32_t n_chains, int64_t 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void uniform_fill_kernel(uint32_t k0, uint32_t k1, int64_t n,
+                                                           double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; 2 * i < n; i += stride) {
+        const u32x4 r = philox4x32_10(u32x4{(uint32_t)i, (uint32_t)((uint64_t)i >> 32),
+                                            STREAM_UNIFORM, 0u}, k0, k1);
+        out[2 * i] = u53_open0(r.x, r.y);
+        if (2 * i + 1 < n) out[2 * i + 1] = u53_open0(r.z, r.w);
+    }
+}
+
+hipError_t launch_uniform_fill(uint64_t seed, int64_t n, double* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = ((n + 1) / 2 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(uniform_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), n, out);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void philox_raw_kernel(uint32_t k0, uint32_t k1,
                                                          uint32_t stream, int64_t n4,
                                                          uint32_t* __restrict__ out) {
