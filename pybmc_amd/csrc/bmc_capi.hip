@@ -104,9 +104,12 @@ Panels panels_of(const bmc_ctx* c, const void* X) {
     return P;
 }
 
-// rows per lane: wide (16-byte) reads once there are enough panels to occupy the
-// chip; narrower panels for small N so that more waves share one pass.
-int choose_vec(int64_t n, int f32) {
+// rows per lane: one row per lane whenever the whole matrix can stay in the chip's VGPRs
+// (256 CUs x 8 waves x ppw panels of 64 rows); otherwise wide (16-byte) reads once there
+// are enough panels to occupy the chip, narrower panels for small N.
+int choose_vec(int64_t n, int32_t k, int f32) {
+    for (int ppw : {1, 2, 4})
+        if (gibbs_reg_capacity(k, f32, ppw) && (n + 63) / 64 <= (int64_t)256 * 8 * ppw) return 1;
     int vec = f32 ? 4 : 2;
     while (vec > 1 && (n + 64 * vec - 1) / (64 * vec) < 1024) vec >>= 1;
     return vec;
@@ -118,7 +121,7 @@ int set_problem_common(bmc_ctx* c, const void* dX, const void* dy, int64_t n, in
     c->n = n;
     c->k = k;
     c->f32 = dtype == BMC_F32;
-    c->vec = choose_vec(n, c->f32);
+    c->vec = choose_vec(n, k, c->f32);
     const int RP = 64 * c->vec;
     c->npanels = (int32_t)((n + RP - 1) / RP);
     const size_t es = c->f32 ? 4 : 8;
@@ -211,10 +214,17 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
         for (int ppw : {1, 2, 4}) {
             if (tu.panels_per_wave > 0 && tu.panels_per_wave != ppw) continue;
             if (!gibbs_reg_capacity(c->k, c->f32, ppw)) continue;
-            // all 32 CUs of the XCD (measured: 32 groups x 5 waves beats 20 x 8 at C2)
-            int G = tu.groups_per_chain > 0 ? tu.groups_per_chain
-                                            : (NP < CU_PER_XCD ? NP : CU_PER_XCD);
-            if (G > CU_PER_XCD) continue;
+            // one XCD (32 CUs) per chain while the panels fit there (measured: 32 groups x 5
+            // waves beats 20 x 8 at C2); otherwise the whole chip serves one chain at a time
+            int G = tu.groups_per_chain;
+            if (G <= 0) {
+                G = NP < CU_PER_XCD ? NP : CU_PER_XCD;
+                if ((int64_t)G * 8 * ppw < NP) {
+                    G = (int)((NP + 8 * ppw - 1) / (8 * ppw));
+                    if (G > MAX_GROUPS_PER_LAUNCH) continue;
+                }
+            }
+            if (G > MAX_GROUPS_PER_LAUNCH) continue;
             const int ppg_reg = (NP + G - 1) / G;
             int waves = tu.waves_per_group > 0 ? tu.waves_per_group : (ppg_reg + ppw - 1) / ppw;
             if (waves > 8 || (int64_t)G * waves * ppw < NP) continue;
@@ -222,8 +232,14 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
             g.ppw = ppw;
             g.G = G;
             g.waves = waves;
-            g.nslot = XCD_COUNT;
-            g.chains_per_launch = n_chains < XCD_COUNT ? n_chains : XCD_COUNT;
+            if (G <= CU_PER_XCD) {
+                g.nslot = XCD_COUNT;
+                g.chains_per_launch = n_chains < XCD_COUNT ? n_chains : XCD_COUNT;
+            } else {
+                g.chains_per_launch = MAX_GROUPS_PER_LAUNCH / G;
+                if (g.chains_per_launch > n_chains) g.chains_per_launch = n_chains;
+                g.nslot = g.chains_per_launch;
+            }
             g.ppg = (NP + G - 1) / G;
             return g;
         }

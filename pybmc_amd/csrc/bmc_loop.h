@@ -144,20 +144,30 @@ template <typename T, int VEC>
 __device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* __restrict__ yp,
                                             const double* __restrict__ u, int K) {
     constexpr int RP = 64 * VEC;
+    // 16 columns per step: 16 independent 64*VEC*sizeof(T)-byte reads in flight per wave
+    // (only ~8 waves run per CU, so the depth has to come from each wave), two FMA chains.
+    constexpr int UN = 16;
     double a0[VEC], a1[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { a0[v] = (double)yp[v]; a1[v] = 0.0; }
     int j = 0;
-#pragma unroll 4
-    for (; j + 1 < K; j += 2) {
-        const double u0 = u[j], u1 = u[j + 1];
+    for (; j + UN <= K; j += UN) {
+        T x[UN][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            a0[v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[v]);
-            a1[v] = fma(-(double)xp[(size_t)(j + 1) * RP + v], u1, a1[v]);
+        for (int q = 0; q < UN; ++q)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[q][v] = xp[(size_t)(j + q) * RP + v];
+#pragma unroll
+        for (int q = 0; q < UN; q += 2) {
+            const double u0 = u[j + q], u1 = u[j + q + 1];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                a0[v] = fma(-(double)x[q][v], u0, a0[v]);
+                a1[v] = fma(-(double)x[q + 1][v], u1, a1[v]);
+            }
         }
     }
-    if (j < K) {
+    for (; j < K; ++j) {
         const double u0 = u[j];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) a0[v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[v]);
@@ -170,6 +180,15 @@ __device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* _
     }
     return s;
 }
+
+// A value the compiler must re-read from its register at this point: keeps f32 panel data
+// as f32 VGPRs (one register per element) instead of hoisting the f32->f64 conversion out
+// of the iteration loop, which would double the register footprint.
+__device__ __forceinline__ double as_f64_in_loop(float x) {
+    asm volatile("" : "+v"(x));
+    return (double)x;
+}
+__device__ __forceinline__ double as_f64_in_loop(double x) { return x; }
 
 // ---- the group's row panels, pinned on chip (or streamed) ---------------------------
 // Group g owns panels g, g+G, ...; wave w of the group handles local panels w, w+nw, ...
@@ -238,10 +257,10 @@ struct PanelStore {
                 const double u0 = u_lds[j], u1 = u_lds[j + 1], u2 = u_lds[j + 2], u3 = u_lds[j + 3];
 #pragma unroll
                 for (int i = 0; i < PPW; ++i) {
-                    acc[i][0] = fma(-(double)xr[i][j], u0, acc[i][0]);
-                    acc[i][1] = fma(-(double)xr[i][j + 1], u1, acc[i][1]);
-                    acc[i][2] = fma(-(double)xr[i][j + 2], u2, acc[i][2]);
-                    acc[i][3] = fma(-(double)xr[i][j + 3], u3, acc[i][3]);
+                    acc[i][0] = fma(-as_f64_in_loop(xr[i][j]), u0, acc[i][0]);
+                    acc[i][1] = fma(-as_f64_in_loop(xr[i][j + 1]), u1, acc[i][1]);
+                    acc[i][2] = fma(-as_f64_in_loop(xr[i][j + 2]), u2, acc[i][2]);
+                    acc[i][3] = fma(-as_f64_in_loop(xr[i][j + 3]), u3, acc[i][3]);
                 }
             }
 #pragma unroll

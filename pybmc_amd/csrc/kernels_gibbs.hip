@@ -381,13 +381,13 @@ static hipError_t launch_one(SimplexTag, const SimplexArgs& a, hipStream_t s) {
 template <typename Tag, typename Args, typename T, int KMAX>
 static hipError_t launch_reg(const Args& a, hipStream_t s) {
     switch (a.reg_ppw) {
-        // panel data is held as f64: PPW * KMAX * 2 <= 128 VGPRs keeps the kernel spill-free
+        // PPW * KMAX * (registers per element) <= 128 data VGPRs keeps the kernel spill-free
         case 1: return launch_one<T, 1, MODE_REG, KMAX, 1>(Tag{}, a, s);
         case 2:
-            if constexpr (KMAX <= 32) return launch_one<T, 1, MODE_REG, KMAX, 2>(Tag{}, a, s);
+            if constexpr (KMAX * sizeof(T) <= 256) return launch_one<T, 1, MODE_REG, KMAX, 2>(Tag{}, a, s);
             break;
         case 4:
-            if constexpr (KMAX <= 16) return launch_one<T, 1, MODE_REG, KMAX, 4>(Tag{}, a, s);
+            if constexpr (KMAX * sizeof(T) <= 128) return launch_one<T, 1, MODE_REG, KMAX, 4>(Tag{}, a, s);
             break;
     }
     return hipErrorInvalidValue;
@@ -418,11 +418,10 @@ static hipError_t launch_t(const Args& a, hipStream_t s) {
 }
 
 int gibbs_reg_capacity(int k, int f32, int ppw) {
-    // data VGPRs per lane (held as f64 for both storage types): ppw * kmax * 2 <= 128
-    (void)f32;
+    // data VGPRs per lane: f64 panels take two registers per element, f32 panels one
     if (k > 64) return 0;
     const int kmax = k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64;
-    return ppw * kmax * 2 <= 128 ? 1 : 0;
+    return ppw * kmax * (f32 ? 1 : 2) <= 128 ? 1 : 0;
 }
 
 template <typename Args>
