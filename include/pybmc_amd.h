@@ -46,7 +46,7 @@ enum { BMC_RNG_DEVICE = 0, BMC_RNG_REPLAY = 1 };
 /* Launch geometry knobs (0 = let the library choose). */
 typedef struct {
     int32_t groups_per_chain; /* workgroups that share one chain's rows        */
-    int32_t waves_per_group;  /* 1..16 (workgroup = 64 * waves threads)        */
+    int32_t waves_per_group;  /* 1..8 (workgroup = 64 * waves threads)         */
     int32_t residency;        /* 0 auto, 1 registers, 2 LDS, 3 stream from HBM */
     int32_t panels_per_wave;  /* register residency: 1, 2 or 4                 */
     int32_t force_agent_scope;/* 1 = never use the XCD-local (L2) exchange     */
@@ -92,6 +92,22 @@ int bmc_set_problem(bmc_ctx* ctx, const void* X, int64_t n, int32_t k, int64_t l
                     int layout, const void* y, int dtype);
 int bmc_set_problem_device(bmc_ctx* ctx, const void* dX, int64_t n, int32_t k,
                            int64_t ldx, int layout, const void* dy, int dtype);
+
+/* ---- orthogonalize on the device -----------------------------------------------------
+ * Replaces the numerical part of BayesianModelCombination.orthogonalize,
+ * pybmc/bmc.py:106-122, and USVt_hat_extraction, pybmc/inference_utils.py:147-168:
+ *   mu = row mean of F over the models, y_c = truth - mu, Fc = F - mu          (:106-116)
+ *   SVD of Fc through its Gram (f64 MFMA): Fc'Fc = V S^2 V', U_hat = Fc V_k S_k^-1   (:119,:164)
+ * F is [n][n_models] with row stride ldf (host).  Outputs (any may be NULL): mean_out [n],
+ * yc_out [n], U_hat_out [k][n] (= an (n,k) array in Fortran order, the layout of :164),
+ * S_out [k], Vt_out [k][n_models] (rows of V'; Vt_hat of :166 is Vt_out[i] / S_out[i]).
+ * Each right singular vector is signed so that its largest entry is positive (LAPACK's signs
+ * are arbitrary; the model weights do not depend on them).  On return the context holds the
+ * problem (y = y_c, X = U_hat) exactly as after bmc_set_problem, without a host round trip.
+ * BMC_ESINGULAR when k reaches the null space of Fc (rows sum to zero: rank <= n_models-1). */
+int bmc_orthogonalize(bmc_ctx* ctx, const double* F, int64_t n, int32_t n_models, int64_t ldf,
+                      const double* truth, int32_t k, double* mean_out, double* yc_out,
+                      double* U_hat_out, double* S_out, double* Vt_out);
 
 /* ---- prior: prior_info = [b0 (k,), C0 (k,k row-major), nu0, sigma20] --------
  * Replaces inference_utils.py:21-37: P = inv(C0) (:22), inv(X'X) and the OLS

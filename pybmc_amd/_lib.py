@@ -54,6 +54,8 @@ PROTOTYPES = {
     "bmc_set_problem": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int, _P, C.c_int]),
     "bmc_set_problem_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int, _P,
                                          C.c_int]),
+    "bmc_orthogonalize": (C.c_int, [_P, _D, C.c_int64, C.c_int32, C.c_int64, _D, C.c_int32, _D, _D, _D,
+                                    _D, _D]),
     "bmc_set_prior": (C.c_int, [_P, _D, _D, C.c_double, C.c_double]),
     "bmc_get_gram": (C.c_int, [_P, _D]),
     "bmc_get_basis": (C.c_int, [_P, _D, _D, _D]),
@@ -186,6 +188,22 @@ class Context:
         self._check(self._lib.bmc_set_problem_device(
             self._h, _P(x_ptr), n, k, ldx, layout, _P(y_ptr), BMC_F32 if f32 else BMC_F64))
         self.n, self.k = n, k
+
+    def orthogonalize(self, F, truth, k, want_U=True):
+        """Centre + thin SVD through the Gram on the device.  Returns
+        (mu, y_c, U_hat or None, S_hat, Vt_rows); the context then holds (y_c, U_hat)."""
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        truth = np.ascontiguousarray(truth, dtype=np.float64).reshape(-1)
+        n, km = F.shape
+        if truth.shape[0] != n:
+            raise ValueError("truth must have one value per row of F")
+        mu, yc = np.empty(n), np.empty(n)
+        U = np.empty((k, n)) if want_U else None
+        S, Vt = np.empty(k), np.empty((k, km))
+        self._check(self._lib.bmc_orthogonalize(self._h, _dptr(F), n, km, km, _dptr(truth), int(k),
+                                                _dptr(mu), _dptr(yc), _dptr(U), _dptr(S), _dptr(Vt)))
+        self.n, self.k = n, int(k)
+        return mu, yc, (U.T if U is not None else None), S, Vt
 
     def set_prior(self, b0, C0, nu0, sigma20):
         b0 = np.ascontiguousarray(b0, dtype=np.float64).reshape(-1)

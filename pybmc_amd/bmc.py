@@ -44,27 +44,52 @@ class BayesianModelCombination:
         self.U_hat = self.S_hat = self.Vt_hat = self.Vt_hat_normalized = None
         self._predictions_mean_train = None
         self.last_stats = None
+        self._device_problem = None
 
     # ------------------------------------------------------------------ set-up
-    def orthogonalize(self, property, train_df, components_kept):
+    def orthogonalize(self, property, train_df, components_kept, method="auto"):
         """Centre the model predictions and keep ``components_kept`` SVD components
-        (reference bmc.py:79-130).  A thin SVD is used: its leading columns equal the
-        reference's full-matrices ones and it does not need O(N^2) memory."""
+        (reference bmc.py:79-130).
+
+        ``method="svd"``: host thin SVD -- its leading columns equal the reference's
+        full-matrices ones (same LAPACK, same signs) without the O(N^2) memory.
+        ``method="device"``: centring, Gram (f64 MFMA), K x K eigen-decomposition and
+        U_hat = Fc V S^-1 on the GPU (``bmc_orthogonalize``); works at sizes where the
+        reference's full SVD cannot run (N = 200000 needs a 320 GB U).  Singular vectors are
+        then signed by their largest entry; the model weights do not depend on the signs.
+        ``"auto"`` picks the device route from 20000 rows on."""
         self.current_property = property
         self.selected_models_dataset = self.data_dict[property].copy()
         F = train_df[self.models].values
         k = int(components_kept)
         if k < 1 or k > min(F.shape):
             raise ValueError("components_kept must be between 1 and min(n_rows, n_models)")
-        mu = np.mean(F, axis=1)
-        y_c = train_df[self.truth_column_name].values - mu
-        Fc = F - mu[:, None]
-        U, S, Vt = np.linalg.svd(Fc, full_matrices=False)
-        if S[k - 1] <= S[0] * 1e-13 * max(F.shape):
-            raise ValueError(
-                "components_kept reaches the null space of the centred model matrix "
-                "(rows sum to zero, so at most n_models - 1 components carry signal)")
-        U_hat, S_hat, Vt_hat, Vt_norm = USVt_hat_extraction(U, S, Vt, k)
+        if method not in ("auto", "svd", "device"):
+            raise ValueError("method must be 'auto', 'svd' or 'device'")
+        if method == "auto":
+            method = "device" if F.shape[0] >= 20000 else "svd"
+        self._device_problem = None
+        if method == "device":
+            from . import _lib
+            ctx = _lib.default_context(self.device)
+            try:
+                mu, y_c, U_hat, S_hat, Vt_norm = ctx.orthogonalize(
+                    F, train_df[self.truth_column_name].values, k)
+            except np.linalg.LinAlgError as e:
+                raise ValueError(str(e)) from None
+            U_hat = np.asfortranarray(U_hat)
+            Vt_hat = Vt_norm / S_hat[:, None]
+            self._device_problem = (ctx, U_hat, y_c)   # the context already holds (y_c, U_hat)
+        else:
+            mu = np.mean(F, axis=1)
+            y_c = train_df[self.truth_column_name].values - mu
+            Fc = F - mu[:, None]
+            U, S, Vt = np.linalg.svd(Fc, full_matrices=False)
+            if S[k - 1] <= S[0] * 1e-13 * max(F.shape):
+                raise ValueError(
+                    "components_kept reaches the null space of the centred model matrix "
+                    "(rows sum to zero, so at most n_models - 1 components carry signal)")
+            U_hat, S_hat, Vt_hat, Vt_norm = USVt_hat_extraction(U, S, Vt, k)
         self.centered_experiment_train = y_c
         self.U_hat, self.S_hat = U_hat, S_hat
         self.Vt_hat, self.Vt_hat_normalized = Vt_hat, Vt_norm
@@ -95,15 +120,19 @@ class BayesianModelCombination:
         sigma20 = get_option("sigma20_chosen", 0.02)
 
         if sampler == "simplex":
+            self._device_problem = None   # the simplex path sets its own problem
             self.samples = gibbs_sampler_simplex(
                 self.centered_experiment_train, self.U_hat, self.Vt_hat, self.S_hat,
                 iterations, [nu0, sigma20], burn=burn, stepsize=stepsize, device=self.device)
         else:
+            dp = self._device_problem
+            on_device = (dp is not None and dp[1] is self.U_hat
+                         and dp[2] is self.centered_experiment_train)
             res, stats = gibbs_sampler(
                 self.centered_experiment_train, self.U_hat, iterations,
                 [b_mean_prior, b_mean_cov, nu0, sigma20],
                 n_chains=int(opts.get("n_chains", 1)), seeds=opts.get("seeds"),
-                device=self.device, return_stats=True)
+                device=self.device, return_stats=True, _problem_on_device=on_device)
             self.last_stats = stats
             # several chains are pooled along the sample axis
             self.samples = res if res.ndim == 2 else res.reshape(-1, res.shape[-1])

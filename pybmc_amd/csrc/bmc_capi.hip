@@ -2,6 +2,7 @@
 // every O(N) step is a gfx950 kernel; the host does the one-off K x K algebra.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -54,6 +55,7 @@ struct bmc_ctx {
     // predictive buffers
     DevBuf pPreds, pTheta, pVt, pWt, pSig, pR, pNoise, pAux, pBands;
     DevBuf sVt, sStep, sUnif, sOut, sCnt;
+    DevBuf oFc, oMu, oW, oOut;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -115,6 +117,8 @@ int choose_vec(int64_t n, int32_t k, int f32) {
     return vec;
 }
 
+int finish_problem(bmc_ctx* c);
+
 int set_problem_common(bmc_ctx* c, const void* dX, const void* dy, int64_t n, int32_t k,
                        int64_t ldx, int layout, int dtype) {
     c->have_problem = c->have_prior = false;
@@ -131,6 +135,13 @@ int set_problem_common(bmc_ctx* c, const void* dX, const void* dy, int64_t n, in
     if ((rc = ensure(c, c->Yp, (size_t)c->npanels * RP * es))) return rc;
     HIPCHK(c, launch_panelize(dX, dy, n, k, ldx, layout == BMC_COL_MAJOR, c->f32, c->vec,
                               c->Xraw.p, c->Yp.p, c->npanels, c->stream));
+    return finish_problem(c);
+}
+
+// Gram of the panelised problem -> host copy; marks the problem as set.
+int finish_problem(bmc_ctx* c) {
+    const int32_t k = c->k;
+    int rc;
     const Panels P = panels_of(c, c->Xraw.p);
     if ((rc = ensure(c, c->gramScratch, gram_scratch_bytes(P)))) return rc;
     const size_t gsz = (size_t)(k + 1) * (k + 1);
@@ -271,7 +282,7 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
     const bool want_stream = tu.residency == RES_STREAM;
     g.mode = (!want_stream && lds_fits(G)) ? 1 : 2;
     int waves = t_waves > 0 ? t_waves : (g.ppg < 4 ? g.ppg : (g.mode == 1 ? (g.ppg < 8 ? g.ppg : 8) : 8));
-    if (waves > 16) waves = 16;
+    if (waves > 8) waves = 8;   // 512-thread workgroups: 256 VGPRs per lane, no spills
     if (waves < 1) waves = 1;
     g.waves = waves;
     // one slot per XCD while a chain's groups fit one XCD's CUs; otherwise any placement
@@ -451,7 +462,7 @@ void bmc_destroy(bmc_ctx* c) {
                       &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
                       &c->seeds, &c->dbg, &c->placement, &c->pPreds, &c->pTheta, &c->pVt,
                       &c->pWt, &c->pSig, &c->pR, &c->pNoise, &c->pAux, &c->pBands, &c->sVt,
-                      &c->sStep, &c->sUnif, &c->sOut, &c->sCnt})
+                      &c->sStep, &c->sUnif, &c->sOut, &c->sCnt, &c->oFc, &c->oMu, &c->oW, &c->oOut})
         release(*b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -483,10 +494,10 @@ int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
         return BMC_OK;
     }
     if (t->groups_per_chain < 0 || t->groups_per_chain > 256 || t->waves_per_group < 0 ||
-        t->waves_per_group > 16 || t->residency < 0 || t->residency > 3 ||
+        t->waves_per_group > 8 || t->residency < 0 || t->residency > 3 ||
         (t->panels_per_wave != 0 && t->panels_per_wave != 1 && t->panels_per_wave != 2 &&
          t->panels_per_wave != 4))
-        return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..16, residency 0..3, "
+        return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..8, residency 0..3, "
                                    "panels_per_wave 0/1/2/4)");
     c->tune = *t;
     return BMC_OK;
@@ -614,10 +625,109 @@ int bmc_set_prior(bmc_ctx* c, const double* b0, const double* C0, double nu0, do
     HIPCHK(c, hipMemcpyAsync(c->dLam.p, c->lam.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dC1.p, c->c1.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dC2.p, c->c2.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_rotate(panels_of(c, c->Xraw.p), (const double*)c->dW.p, c->Xrot.p, c->stream));
+    HIPCHK(c, launch_rotate(panels_of(c, c->Xraw.p), (const double*)c->dW.p, c->k, c->Xrot.p,
+                            c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // WT (stack vector) must outlive the copy
     c->have_prior = true;
     return BMC_OK;
+}
+
+int bmc_orthogonalize(bmc_ctx* c, const double* F, int64_t n, int32_t km, int64_t ldf,
+                      const double* truth, int32_t k, double* mean_out, double* yc_out,
+                      double* U_hat_out, double* S_out, double* Vt_out) {
+    if (!c) return BMC_EINVAL;
+    if (!F || !truth) return fail(c, BMC_EINVAL, "F and truth must not be NULL");
+    if (n < 1 || km < 1 || k < 1 || k > km || ldf < km)
+        return fail(c, BMC_EINVAL, "need n >= 1, 1 <= components_kept <= n_models, ldf >= n_models");
+    if (km > 255) return fail(c, BMC_EINVAL, "more than 255 models is not supported");
+    if (k > n) return fail(c, BMC_EINVAL, "components_kept exceeds the number of rows");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->have_problem = c->have_prior = false;
+    // panels of the centred matrix use the row-per-lane choice of the FINAL (n x k) problem
+    const int vec = choose_vec(n, k, 0);
+    const int RP = 64 * vec;
+    const int32_t npanels = (int32_t)((n + RP - 1) / RP);
+    int rc;
+    const size_t fbytes = (size_t)((size_t)ldf * (n - 1) + km) * 8;
+    const size_t toff = (fbytes + 255) & ~(size_t)255;
+    if ((rc = ensure(c, c->stage, toff + (size_t)n * 8)) ||
+        (rc = ensure(c, c->oFc, (size_t)npanels * km * RP * 8)) ||
+        (rc = ensure(c, c->Yp, (size_t)npanels * RP * 8)) ||
+        (rc = ensure(c, c->oMu, (size_t)npanels * RP * 8)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->stage.p, F, fbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char*)c->stage.p + toff, truth, (size_t)n * 8, hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, launch_centre((const double*)c->stage.p, n, km, ldf,
+                            (const double*)((char*)c->stage.p + toff), vec, npanels,
+                            (double*)c->oFc.p, (double*)c->Yp.p, (double*)c->oMu.p, c->stream));
+    // Gram of the centred matrix: Fc'Fc = V S^2 V'  (the SVD of bmc.py:119 through its Gram)
+    Panels P;
+    P.X = c->oFc.p; P.y = c->Yp.p; P.n = n; P.k = km; P.vec = vec; P.npanels = npanels; P.f32 = 0;
+    const size_t gsz = (size_t)(km + 1) * (km + 1);
+    if ((rc = ensure(c, c->gramScratch, gram_scratch_bytes(P))) ||
+        (rc = ensure(c, c->gramOut, gsz * 8)))
+        return rc;
+    HIPCHK(c, launch_gram(P, c->gramScratch.p, (double*)c->gramOut.p, c->stream));
+    std::vector<double> ga(gsz);
+    HIPCHK(c, hipMemcpyAsync(ga.data(), c->gramOut.p, gsz * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bmc_la::Mat Gm((size_t)km * km), Q;
+    for (int i = 0; i < km; ++i)
+        for (int j = 0; j < km; ++j) Gm[(size_t)i * km + j] = ga[(size_t)i * (km + 1) + j];
+    std::vector<double> ev;
+    bmc_la::jacobi_eigh(Gm, km, ev, Q);
+    std::vector<int> order(km);
+    for (int i = 0; i < km; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return ev[a] > ev[b]; });
+    const double s0 = std::sqrt(ev[order[0]] > 0 ? ev[order[0]] : 0.0);
+    const double sk = std::sqrt(ev[order[k - 1]] > 0 ? ev[order[k - 1]] : 0.0);
+    // rows of the centred matrix sum to zero -> rank <= n_models - 1 (bmc.py:114-119); the
+    // Gram route also loses accuracy like (s0/sk)^2, so refuse ill-conditioned requests
+    if (!(sk > s0 * 1e-6) || !(s0 > 0))
+        return fail(c, BMC_ESINGULAR,
+                    "components_kept reaches the (numerical) null space of the centred model matrix");
+    std::vector<double> W((size_t)km * k), Vt((size_t)k * km), S(k);
+    for (int q = 0; q < k; ++q) {
+        const int col = order[q];
+        S[q] = std::sqrt(ev[col]);
+        // sign convention: the entry of largest magnitude of each right singular vector is > 0
+        int big = 0;
+        for (int i = 1; i < km; ++i)
+            if (std::fabs(Q[(size_t)i * km + col]) > std::fabs(Q[(size_t)big * km + col])) big = i;
+        const double sg = Q[(size_t)big * km + col] < 0 ? -1.0 : 1.0;
+        for (int i = 0; i < km; ++i) {
+            const double v = sg * Q[(size_t)i * km + col];
+            Vt[(size_t)q * km + i] = v;
+            W[(size_t)i * k + q] = v / S[q];          // U_hat = Fc V S^-1
+        }
+    }
+    // the sampler's problem: X = U_hat (n x k panels), y = centred truth
+    c->n = n;
+    c->k = k;
+    c->f32 = 0;
+    c->vec = vec;
+    c->npanels = npanels;
+    if ((rc = ensure(c, c->Xraw, (size_t)npanels * k * RP * 8)) ||
+        (rc = ensure(c, c->Xrot, (size_t)npanels * k * RP * 8)) ||
+        (rc = ensure(c, c->oW, W.size() * 8)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->oW.p, W.data(), W.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rotate(P, (const double*)c->oW.p, k, c->Xraw.p, c->stream));
+    if (U_hat_out) {
+        if ((rc = ensure(c, c->oOut, (size_t)n * k * 8))) return rc;
+        HIPCHK(c, launch_unpanelize((const double*)c->Xraw.p, n, k, vec, (double*)c->oOut.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(U_hat_out, c->oOut.p, (size_t)n * k * 8, hipMemcpyDeviceToHost,
+                                 c->stream));
+    }
+    if (mean_out)
+        HIPCHK(c, hipMemcpyAsync(mean_out, c->oMu.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (yc_out)
+        HIPCHK(c, hipMemcpyAsync(yc_out, c->Yp.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // W (host vector) must outlive its copy
+    if (S_out) std::memcpy(S_out, S.data(), (size_t)k * 8);
+    if (Vt_out) std::memcpy(Vt_out, Vt.data(), (size_t)k * km * 8);
+    return finish_problem(c);
 }
 
 int bmc_get_gram(bmc_ctx* c, double* out) {

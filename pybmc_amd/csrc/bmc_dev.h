@@ -33,17 +33,26 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Sum over the 64 lanes; every lane returns the same bits.  The order is fixed
-// (quad xor 1, quad xor 2, half-row mirror, row mirror, then rows 0..3 in
-// order), so the result does not depend on timing or placement.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_rows_f64(double v) {  // 0.0 in the rows not selected
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes; every lane returns the same bits.  The order is fixed (quad xor 1,
+// quad xor 2, half-row mirror, row mirror -> every lane holds its row total r0..r3; then
+// row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3 -> lane 63 holds
+// (r2 + r3) + (r0 + r1)), so the result does not depend on timing or placement.
 __device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov_f64<0x141>(v);  // row_half_mirror
-    v += dpp_mov_f64<0x140>(v);  // row_mirror
-    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
-    const double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-    return ((r0 + r1) + r2) + r3;
+    v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);         // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);         // row_mirror
+    v += dpp_rows_f64<0x142, 0xA>(v);   // row_bcast15 -> rows 1 and 3
+    v += dpp_rows_f64<0x143, 0xC>(v);   // row_bcast31 -> rows 2 and 3
+    return readlane_f64(v, 63);
 }
 
 // ---- inter-workgroup granules (cdna guide, Guideline 16 form R2) -------------

@@ -27,8 +27,16 @@ hipError_t launch_panelize(const void* Xsrc, const void* ysrc, int64_t n, int32_
 size_t gram_scratch_bytes(const Panels& P);
 hipError_t launch_gram(const Panels& P, void* scratch, double* gram_out, hipStream_t s);
 
-// Xrot = X * W (W k x k row-major, device), same panel layout and storage type.
-hipError_t launch_rotate(const Panels& P, const double* W, void* Xrot, hipStream_t s);
+// Xrot = X * W (W is P.k x ko row-major, device); output panels have ko columns, same
+// rows per lane and storage type.
+hipError_t launch_rotate(const Panels& P, const double* W, int32_t ko, void* Xrot, hipStream_t s);
+
+// orthogonalize helpers: centring into panels, panels -> column-major
+hipError_t launch_centre(const double* F, int64_t n, int32_t km, int64_t ldf, const double* truth,
+                         int32_t vec, int32_t npanels, double* Fc, double* yc, double* mu,
+                         hipStream_t s);
+hipError_t launch_unpanelize(const double* Xp, int64_t n, int32_t k, int32_t vec, double* out,
+                             hipStream_t s);
 
 // rss[b] = sum_i (y_i - sum_j X_ij coef[b][j])^2, b < nb (nb <= 8), one launch.
 // partial: >= rss_groups(P) * 8 doubles of scratch; ticket_word: one zeroed u32 that

@@ -41,7 +41,7 @@
 namespace bmc {
 
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
-__global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kernel(GibbsArgs a) {
+__global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = a.P.k;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void gibbs_loop_kern
 // the exchange epoch counts exchanges, not iterations.
 // ======================================================================================
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
-__global__ __launch_bounds__(MODE == MODE_REG ? 512 : 1024) void simplex_loop_kernel(SimplexArgs a) {
+__global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
     constexpr int RP = 64 * VEC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = a.P.k, Km = a.Km, G = a.G;
@@ -396,7 +396,7 @@ static hipError_t launch_reg(const Args& a, hipStream_t s) {
 template <typename Tag, typename Args, typename T>
 static hipError_t launch_t(const Args& a, hipStream_t s) {
     if (a.mode == MODE_REG) {
-        if (a.P.vec != 1 || a.waves > 8) return hipErrorInvalidValue;
+        if (a.P.vec != 1) return hipErrorInvalidValue;
         if (a.P.k <= 8) return launch_reg<Tag, Args, T, 8>(a, s);
         if (a.P.k <= 16) return launch_reg<Tag, Args, T, 16>(a, s);
         if (a.P.k <= 32) return launch_reg<Tag, Args, T, 32>(a, s);
@@ -427,7 +427,7 @@ int gibbs_reg_capacity(int k, int f32, int ppw) {
 template <typename Args>
 static bool geometry_ok(const Args& a) {
     return a.P.k <= 64 * MAX_KCH && a.G <= 32 * MAX_GRAN_REG && a.G >= 1 && a.waves >= 1 &&
-           a.waves <= 16 && a.nslot >= 1 && a.nslot <= 256;
+           a.waves <= 8 && a.nslot >= 1 && a.nslot <= 256;
 }
 
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {

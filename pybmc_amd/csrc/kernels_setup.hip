@@ -215,12 +215,13 @@ constexpr int ROT_JT = 8;
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void rotate_kernel(const T* __restrict__ X,
                                                      const double* __restrict__ W, int32_t K,
-                                                     T* __restrict__ Xrot) {
+                                                     int32_t KO, T* __restrict__ Xrot) {
+    // W is [K][KO] row-major; the output panels have KO columns
     constexpr int RP = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = (blockIdx.y * 4 + wave) * ROT_JT;
-    if (j0 >= K) return;
+    if (j0 >= KO) return;
     const int64_t p = blockIdx.x;
     const T* xp = X + p * (int64_t)K * RP + lane * VEC;
     double acc[ROT_JT][VEC];
@@ -234,25 +235,26 @@ __global__ __launch_bounds__(256) void rotate_kernel(const T* __restrict__ X,
         for (int v = 0; v < VEC; ++v) x[v] = (double)xp[(int64_t)i * RP + v];
 #pragma unroll
         for (int q = 0; q < ROT_JT; ++q) {
-            const double w = (j0 + q < K) ? W[(size_t)i * K + j0 + q] : 0.0;
+            const double w = (j0 + q < KO) ? W[(size_t)i * KO + j0 + q] : 0.0;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[q][v] = fma(x[v], w, acc[q][v]);
         }
     }
-    T* op = Xrot + p * (int64_t)K * RP + lane * VEC;
+    T* op = Xrot + p * (int64_t)KO * RP + lane * VEC;
 #pragma unroll
     for (int q = 0; q < ROT_JT; ++q)
-        if (j0 + q < K)
+        if (j0 + q < KO)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) op[(int64_t)(j0 + q) * RP + v] = (T)acc[q][v];
 }
 
 template <typename T>
-static hipError_t rotate_dispatch(const Panels& P, const double* W, void* Xrot, hipStream_t s) {
-    dim3 grid(P.npanels, (P.k + 4 * ROT_JT - 1) / (4 * ROT_JT));
+static hipError_t rotate_dispatch(const Panels& P, const double* W, int32_t ko, void* Xrot,
+                                  hipStream_t s) {
+    dim3 grid(P.npanels, (ko + 4 * ROT_JT - 1) / (4 * ROT_JT));
 #define BMC_ROT(V)                                                                       \
     hipLaunchKernelGGL((rotate_kernel<T, V>), grid, dim3(256), 0, s, (const T*)P.X, W, P.k, \
-                       (T*)Xrot)
+                       ko, (T*)Xrot)
     switch (P.vec) {
         case 1: BMC_ROT(1); break;
         case 2: BMC_ROT(2); break;
@@ -263,8 +265,80 @@ static hipError_t rotate_dispatch(const Panels& P, const double* W, void* Xrot, 
     return hipGetLastError();
 }
 
-hipError_t launch_rotate(const Panels& P, const double* W, void* Xrot, hipStream_t s) {
-    return P.f32 ? rotate_dispatch<float>(P, W, Xrot, s) : rotate_dispatch<double>(P, W, Xrot, s);
+hipError_t launch_rotate(const Panels& P, const double* W, int32_t ko, void* Xrot, hipStream_t s) {
+    return P.f32 ? rotate_dispatch<float>(P, W, ko, Xrot, s)
+                 : rotate_dispatch<double>(P, W, ko, Xrot, s);
+}
+
+// =========================================================================
+// orthogonalize helpers (reference bmc.py:106-116 and the layout of inference_utils.py:164)
+// =========================================================================
+// centre: mu_n = mean_j F[n][j]; Fc = F - mu (panels); yc = truth - mu.  One lane per row.
+template <int VEC>
+__global__ __launch_bounds__(256) void centre_kernel(const double* __restrict__ F, int64_t n,
+                                                     int32_t km, int64_t ldf,
+                                                     const double* __restrict__ truth,
+                                                     int32_t npanels, double* __restrict__ Fc,
+                                                     double* __restrict__ yc,
+                                                     double* __restrict__ mu) {
+    constexpr int RP = 64 * VEC;
+    const int64_t total = (int64_t)npanels * RP;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < total; row += stride) {
+        const int64_t p = row / RP;
+        const int32_t r = (int32_t)(row - p * RP);
+        double m = 0.0;
+        if (row < n) {
+            const double* fr = F + row * ldf;
+            for (int j = 0; j < km; ++j) m += fr[j];
+            m /= (double)km;
+            for (int j = 0; j < km; ++j) Fc[(p * km + j) * RP + r] = fr[j] - m;
+            yc[row] = truth[row] - m;
+            mu[row] = m;
+        } else {
+            for (int j = 0; j < km; ++j) Fc[(p * km + j) * RP + r] = 0.0;
+            yc[row] = 0.0;
+        }
+    }
+}
+
+hipError_t launch_centre(const double* F, int64_t n, int32_t km, int64_t ldf, const double* truth,
+                         int32_t vec, int32_t npanels, double* Fc, double* yc, double* mu,
+                         hipStream_t s) {
+    int64_t blocks = ((int64_t)npanels * 64 * vec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (vec == 1)
+        hipLaunchKernelGGL(centre_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, F, n, km, ldf,
+                           truth, npanels, Fc, yc, mu);
+    else if (vec == 2)
+        hipLaunchKernelGGL(centre_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, F, n, km, ldf,
+                           truth, npanels, Fc, yc, mu);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// panels [NP][K][RP] -> column-major [K][n] (what a Fortran-ordered (n, K) numpy array is)
+__global__ __launch_bounds__(256) void unpanelize_kernel(const double* __restrict__ Xp, int64_t n,
+                                                         int32_t k, int32_t RP,
+                                                         double* __restrict__ out) {
+    const int64_t total = n * k;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int32_t j = (int32_t)(e / n);
+        const int64_t row = e - (int64_t)j * n;
+        const int64_t p = row / RP;
+        out[e] = Xp[(p * k + j) * RP + (row - p * RP)];
+    }
+}
+
+hipError_t launch_unpanelize(const double* Xp, int64_t n, int32_t k, int32_t vec, double* out,
+                             hipStream_t s) {
+    int64_t blocks = (n * k + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(unpanelize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Xp, n, k,
+                       64 * vec, out);
+    return hipGetLastError();
 }
 
 // =========================================================================

@@ -21,7 +21,7 @@ def _draw_seeds(n):
 
 
 def gibbs_sampler(y, X, iterations, prior_info, *, n_chains=1, seeds=None, device=0,
-                  dtype=None, return_stats=False):
+                  dtype=None, return_stats=False, _problem_on_device=False):
     """Gibbs sampling for Bayesian linear regression on the GPU.
 
     Same arguments and result as the reference (inference_utils.py:4-20):
@@ -37,7 +37,8 @@ def gibbs_sampler(y, X, iterations, prior_info, *, n_chains=1, seeds=None, devic
     """
     b0, C0, nu0, s20 = prior_info
     ctx = _lib.default_context(device)
-    ctx.set_problem(y, X, dtype=dtype)
+    if not _problem_on_device:   # orthogonalize(method="device") left (y, X) on the GPU
+        ctx.set_problem(y, X, dtype=dtype)
     ctx.set_prior(b0, C0, nu0, s20)
     if seeds is None:
         seeds = _draw_seeds(n_chains)

@@ -82,8 +82,8 @@ def test_t2_replay_is_geometry_independent():
     seen = set()
     for G, W, res, ppw, agent in [(0, 0, 0, 0, 0), (0, 0, 0, 0, 1), (20, 8, 1, 1, 0),
                                   (32, 5, 1, 1, 1), (10, 8, 1, 2, 0), (16, 5, 1, 2, 1),
-                                  (157, 1, 2, 0, 0), (8, 16, 2, 0, 0), (32, 5, 2, 0, 1),
-                                  (64, 3, 3, 0, 0), (256, 1, 2, 0, 0), (1, 16, 3, 0, 0)]:
+                                  (157, 1, 2, 0, 0), (8, 8, 2, 0, 0), (32, 5, 2, 0, 1),
+                                  (64, 3, 3, 0, 0), (256, 1, 2, 0, 0), (1, 8, 3, 0, 0)]:
         ctx.set_tuning(G, W, res, ppw, agent)
         o, stats = ctx.gibbs_run(1, T, xi=xi[None], g=g["G"][None, :T])
         assert np.abs(o[0] - ref).max() < 1e-9, (G, W, res, ppw, agent)
