@@ -125,7 +125,10 @@ def main():
 
     def step(record):
         st = ctx.gibbs_run_device(len(mine), T, seeds, out.data_ptr())
-        pooled = pool_samples(out, n_chains) if world > 1 else out
+        pooled = out
+        if world > 1:
+            pooled = pool_samples(out, n_chains)
+            torch.cuda.synchronize()   # the all-gather has read `out` before the next step rewrites it
         if record:
             loop_ms.append(st["loop_ms"])
             bytes_moved.append(st["passes"] * st["bytes_per_pass"] / max(st["chains_per_pass"], 1))

@@ -42,17 +42,18 @@ __device__ __forceinline__ double dpp_rows_f64(double v) {  // 0.0 in the rows n
 }
 
 // Sum over the 64 lanes; every lane returns the same bits.  The order is fixed (quad xor 1,
-// quad xor 2, half-row mirror, row mirror -> every lane holds its row total r0..r3; then
-// row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3 -> lane 63 holds
-// (r2 + r3) + (r0 + r1)), so the result does not depend on timing or placement.
+// quad xor 2, half-row mirror, row mirror -> every lane holds its row total; then the four
+// row totals in order through the scalar unit), so the result does not depend on timing or
+// placement.  (A/B on one MI355X: finishing with row_bcast15/row_bcast31 DPP steps instead of
+// the four readlanes is 2 % slower per Gibbs iteration.)
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]
     v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
     v += dpp_mov_f64<0x141>(v);         // row_half_mirror
     v += dpp_mov_f64<0x140>(v);         // row_mirror
-    v += dpp_rows_f64<0x142, 0xA>(v);   // row_bcast15 -> rows 1 and 3
-    v += dpp_rows_f64<0x143, 0xC>(v);   // row_bcast31 -> rows 2 and 3
-    return readlane_f64(v, 63);
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
+    const double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return ((r0 + r1) + r2) + r3;
 }
 
 // ---- inter-workgroup granules (cdna guide, Guideline 16 form R2) -------------
