@@ -81,6 +81,31 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  torch's wheel bundles its own libamdhip64.so (same
+    soname as /opt/rocm's); if torch is imported AFTER this library bound the system copy, the
+    process would hold two runtimes and device pointers could not be shared (bench.py and
+    pybmc_amd.chains hand torch tensors to the C ABI).  So when torch is installed but not yet
+    imported, its copy is loaded first; the dynamic loader then resolves our NEEDED entry and
+    torch's own to that one object.  Set PYBMC_AMD_SYSTEM_HIP=1 to skip this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("PYBMC_AMD_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen the in-tree library and bind every prototype.  Raises if absent."""
     global _lib
@@ -91,6 +116,7 @@ def load_library():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C pybmc_amd/csrc` "
                 "(or __graft_entry__.build()).  pybmc_amd has no CPU fallback.")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
