@@ -236,6 +236,33 @@ def main():
                 c4.close()
             except Exception as e:
                 extra["residual_rss_c4"] = {"error": str(e)}
+            try:
+                # the persistent loop at the C4 and C5 sizes (1 chain, as on each GPU of the
+                # 8-GPU configurations); gaussian design matrices scaled to unit-norm columns
+                for tag, n4, k4, dt, iters4 in (("loop_c4", 200000, 64, np.float32, 4000),
+                                                ("loop_c5", 50000, 256, np.float64, 2000)):
+                    rng = np.random.Generator(np.random.PCG64(8))
+                    Xl = (rng.standard_normal((n4, k4)) / np.sqrt(n4)).astype(dt)
+                    yl = (Xl.astype(np.float64) @ rng.standard_normal(k4)
+                          + 0.1 * rng.standard_normal(n4)).astype(dt)
+                    cl = _lib.Context(local_rank)
+                    cl.set_problem(yl, np.asfortranarray(Xl), dtype=dt)
+                    cl.set_prior(np.zeros(k4), np.eye(k4) * 100.0, 1.0, 0.02)
+                    outl = torch.empty((1, iters4, k4 + 1), dtype=torch.float64, device=dev)
+                    cl.gibbs_run_device(1, 200, chain_seeds(1, [0]), outl.data_ptr())
+                    stl = cl.gibbs_run_device(1, iters4, chain_seeds(1, [0]), outl.data_ptr())
+                    bl = stl["bytes_per_pass"]
+                    us = stl["loop_ms"] * 1e3 / iters4
+                    extra[tag] = {"n_obs": n4, "k": k4, "dtype": "f32" if dt == np.float32 else "f64",
+                                  "us_per_iteration": us, "samples_per_s": iters4 / stl["loop_ms"] * 1e3,
+                                  "algorithmic_GBs": bl / us / 1e3,
+                                  "frac_of_8TBs": bl / us / 1e3 / HBM_PEAK_GBS,
+                                  "residency": {1: "vgpr", 2: "lds", 3: "stream"}.get(stl["residency"]),
+                                  "groups": stl["groups_per_chain"], "waves": stl["waves_per_group"]}
+                    del outl, Xl, yl
+                    cl.close()
+            except Exception as e:
+                extra["loop_c4"] = {"error": str(e)}
             line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(prob)

@@ -110,8 +110,14 @@ Panels panels_of(const bmc_ctx* c, const void* X) {
 // (256 CUs x 8 waves x ppw panels of 64 rows); otherwise wide (16-byte) reads once there
 // are enough panels to occupy the chip, narrower panels for small N.
 int choose_vec(int64_t n, int32_t k, int f32) {
-    for (int ppw : {1, 2, 4})
-        if (gibbs_reg_capacity(k, f32, ppw) && (n + 63) / 64 <= (int64_t)256 * 8 * ppw) return 1;
+    // register residency: the narrowest panel that lets every panel have its own wave (more
+    // waves = shorter serial FMA phase); two rows per lane (wider reads for the streaming
+    // kernels that share the layout) once one row per lane would need two panels per wave
+    const int64_t waves_chip = 256 * 8;
+    if (gibbs_reg_capacity(k, f32, 1) && (n + 63) / 64 <= waves_chip) return 1;
+    if (gibbs_reg_capacity(k, f32, 2) && (n + 127) / 128 <= waves_chip) return 2;
+    for (int ppw : {2, 4})
+        if (gibbs_reg_capacity(k, f32, ppw) && (n + 63) / 64 <= waves_chip * ppw) return 1;
     int vec = f32 ? 4 : 2;
     while (vec > 1 && (n + 64 * vec - 1) / (64 * vec) < 1024) vec >>= 1;
     return vec;
@@ -221,10 +227,11 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
     Geometry g{};
     g.ppw = 1;
     // ---- register residency: G <= 32 groups of <= 8 waves, 1/2/4 panels per wave ----
-    if ((tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec == 1) {
+    if ((tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec <= 2) {
         for (int ppw : {1, 2, 4}) {
             if (tu.panels_per_wave > 0 && tu.panels_per_wave != ppw) continue;
-            if (!gibbs_reg_capacity(c->k, c->f32, ppw)) continue;
+            if (c->vec == 2 && ppw != 1) continue;
+            if (!gibbs_reg_capacity(c->k, c->f32, ppw * c->vec)) continue;
             // one XCD (32 CUs) per chain while the panels fit there (measured: 32 groups x 5
             // waves beats 20 x 8 at C2); otherwise the whole chip serves one chain at a time
             int G = tu.groups_per_chain;

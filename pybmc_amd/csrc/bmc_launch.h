@@ -136,7 +136,7 @@ hipError_t launch_simplex(const SimplexArgs& a, hipStream_t s);
 hipError_t launch_uniform_fill(uint64_t seed, int64_t n, double* out, hipStream_t s);
 
 size_t gibbs_lds_bytes(const GibbsArgs& a);
-int gibbs_reg_capacity(int k, int f32, int ppw);  // 1 if ppw panels of k columns fit in VGPRs
+int gibbs_reg_capacity(int k, int f32, int rows_per_lane);  // 1 if that many rows of k columns fit in VGPRs
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s);
 
 }  // namespace bmc

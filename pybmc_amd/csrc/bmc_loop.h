@@ -195,8 +195,8 @@ __device__ __forceinline__ double as_f64_in_loop(double x) { return x; }
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 struct PanelStore {
     static constexpr int RP = 64 * VEC;
-    T xr[PPW > 0 ? PPW : 1][KMAX > 0 ? KMAX : 1];
-    T yr[PPW > 0 ? PPW : 1];
+    T xr[PPW > 0 ? PPW : 1][KMAX > 0 ? KMAX : 1][VEC];   // register mode: VEC rows per lane
+    T yr[PPW > 0 ? PPW : 1][VEC];
     const T* Xg;
     const T* yg;
     T* Xs;
@@ -204,7 +204,6 @@ struct PanelStore {
     int K, G, g, npl, nw, wave, lane;
 
     __device__ __forceinline__ void init(const Panels& P, int G_, int g_, T* Xs_, T* ys_) {
-        static_assert(MODE != MODE_REG || VEC == 1, "register mode keeps one row per lane");
         Xg = reinterpret_cast<const T*>(P.X);
         yg = reinterpret_cast<const T*>(P.y);
         Xs = Xs_;
@@ -226,8 +225,11 @@ struct PanelStore {
                 const int64_t p = g + (int64_t)q * G;
 #pragma unroll
                 for (int j = 0; j < KMAX; ++j)
-                    xr[i][j] = (have && j < K) ? Xg[(p * K + j) * RP + lane] : (T)0;
-                yr[i] = have ? yg[p * RP + lane] : (T)0;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        xr[i][j][v] = (have && j < K) ? Xg[(p * K + j) * RP + lane * VEC + v] : (T)0;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) yr[i][v] = have ? yg[p * RP + lane * VEC + v] : (T)0;
             }
         } else if constexpr (MODE == MODE_LDS) {
             constexpr int EPV = 16 / (int)sizeof(T);
@@ -246,28 +248,34 @@ struct PanelStore {
     __device__ __forceinline__ double partial_rss(const double* __restrict__ u_lds) const {
         double s = 0.0;
         if constexpr (MODE == MODE_REG) {
-            double acc[PPW][4];
+            double acc[PPW][VEC][4];
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                acc[i][0] = (double)yr[i];
-                acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
-            }
+            for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    acc[i][v][0] = (double)yr[i][v];
+                    acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
+                }
 #pragma unroll
             for (int j = 0; j < KMAX; j += 4) {
                 const double u0 = u_lds[j], u1 = u_lds[j + 1], u2 = u_lds[j + 2], u3 = u_lds[j + 3];
 #pragma unroll
-                for (int i = 0; i < PPW; ++i) {
-                    acc[i][0] = fma(-as_f64_in_loop(xr[i][j]), u0, acc[i][0]);
-                    acc[i][1] = fma(-as_f64_in_loop(xr[i][j + 1]), u1, acc[i][1]);
-                    acc[i][2] = fma(-as_f64_in_loop(xr[i][j + 2]), u2, acc[i][2]);
-                    acc[i][3] = fma(-as_f64_in_loop(xr[i][j + 3]), u3, acc[i][3]);
-                }
+                for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        acc[i][v][0] = fma(-as_f64_in_loop(xr[i][j][v]), u0, acc[i][v][0]);
+                        acc[i][v][1] = fma(-as_f64_in_loop(xr[i][j + 1][v]), u1, acc[i][v][1]);
+                        acc[i][v][2] = fma(-as_f64_in_loop(xr[i][j + 2][v]), u2, acc[i][v][2]);
+                        acc[i][v][3] = fma(-as_f64_in_loop(xr[i][j + 3][v]), u3, acc[i][v][3]);
+                    }
             }
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const double r = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
-                s = fma(r, r, s);
-            }
+            for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double r = (acc[i][v][0] + acc[i][v][1]) + (acc[i][v][2] + acc[i][v][3]);
+                    s = fma(r, r, s);
+                }
         } else {
             for (int q = wave; q < npl; q += nw) {
                 if constexpr (MODE == MODE_LDS) {

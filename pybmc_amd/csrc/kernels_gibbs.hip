@@ -380,8 +380,14 @@ static hipError_t launch_one(SimplexTag, const SimplexArgs& a, hipStream_t s) {
 
 template <typename Tag, typename Args, typename T, int KMAX>
 static hipError_t launch_reg(const Args& a, hipStream_t s) {
+    // rows per lane (PPW * VEC) * KMAX * (registers per element) <= 128 data VGPRs keeps the
+    // kernel spill-free; VEC = 2 panels are supported with one panel per wave
+    if (a.P.vec == 2) {
+        if constexpr (KMAX * sizeof(T) <= 256)
+            if (a.reg_ppw == 1) return launch_one<T, 2, MODE_REG, KMAX, 1>(Tag{}, a, s);
+        return hipErrorInvalidValue;
+    }
     switch (a.reg_ppw) {
-        // PPW * KMAX * (registers per element) <= 128 data VGPRs keeps the kernel spill-free
         case 1: return launch_one<T, 1, MODE_REG, KMAX, 1>(Tag{}, a, s);
         case 2:
             if constexpr (KMAX * sizeof(T) <= 256) return launch_one<T, 1, MODE_REG, KMAX, 2>(Tag{}, a, s);
@@ -396,7 +402,7 @@ static hipError_t launch_reg(const Args& a, hipStream_t s) {
 template <typename Tag, typename Args, typename T>
 static hipError_t launch_t(const Args& a, hipStream_t s) {
     if (a.mode == MODE_REG) {
-        if (a.P.vec != 1) return hipErrorInvalidValue;
+        if (a.P.vec != 1 && a.P.vec != 2) return hipErrorInvalidValue;
         if (a.P.k <= 8) return launch_reg<Tag, Args, T, 8>(a, s);
         if (a.P.k <= 16) return launch_reg<Tag, Args, T, 16>(a, s);
         if (a.P.k <= 32) return launch_reg<Tag, Args, T, 32>(a, s);
@@ -417,11 +423,12 @@ static hipError_t launch_t(const Args& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-int gibbs_reg_capacity(int k, int f32, int ppw) {
-    // data VGPRs per lane: f64 panels take two registers per element, f32 panels one
+int gibbs_reg_capacity(int k, int f32, int rows_per_lane) {
+    // data VGPRs per lane: f64 panels take two registers per element, f32 panels one;
+    // rows_per_lane = panels per wave x rows per lane of a panel
     if (k > 64) return 0;
     const int kmax = k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64;
-    return ppw * kmax * (f32 ? 1 : 2) <= 128 ? 1 : 0;
+    return rows_per_lane * kmax * (f32 ? 1 : 2) <= 128 ? 1 : 0;
 }
 
 template <typename Args>
