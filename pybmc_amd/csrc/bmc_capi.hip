@@ -591,7 +591,7 @@ int bmc_set_prior(bmc_ctx* c, const double* b0, const double* C0, double nu0, do
             M[(size_t)i * k + j] = M[(size_t)j * k + i] = v;
         }
     bmc_la::Mat Q;
-    bmc_la::jacobi_eigh(M, k, c->lam, Q);
+    bmc_la::sym_eigh(M, k, c->lam, Q);
     c->W.assign((size_t)k * k, 0.0);
     for (int i = 0; i < k; ++i)          // W = Li' Q
         for (int j = 0; j < k; ++j) {
@@ -683,7 +683,7 @@ int bmc_orthogonalize(bmc_ctx* c, const double* F, int64_t n, int32_t km, int64_
     for (int i = 0; i < km; ++i)
         for (int j = 0; j < km; ++j) Gm[(size_t)i * km + j] = ga[(size_t)i * (km + 1) + j];
     std::vector<double> ev;
-    bmc_la::jacobi_eigh(Gm, km, ev, Q);
+    bmc_la::sym_eigh(Gm, km, ev, Q);
     std::vector<int> order(km);
     for (int i = 0; i < km; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return ev[a] > ev[b]; });
