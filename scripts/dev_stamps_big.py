@@ -1,0 +1,23 @@
+"""Diagnostic: phase shares of one iteration at the C5 size (stamped build)."""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, "/root/repo")
+from pybmc_amd import _lib
+_lib.LIB_PATH = _lib.LIB_PATH.replace("libpybmc_amd.so", "libpybmc_amd_stamps.so")
+lib = _lib.load_library()
+lib.bmc_dev_get_stamps.restype = C.c_int
+lib.bmc_dev_get_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+ctx = _lib.Context(0)
+rng = np.random.Generator(np.random.PCG64(1))
+names = ["u", "B1", "matvec", "-", "-", "wsum..gather", "s2", "top"]
+for name, n, k, dt in (("C5 50000x256 f64", 50000, 256, np.float64), ("C4 200000x64 f32", 200000, 64, np.float32)):
+    X = (rng.standard_normal((n, k)) / np.sqrt(n)).astype(dt)
+    y = (X.astype(float) @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)).astype(dt)
+    ctx.set_problem(y, np.asfortranarray(X), dtype=dt); ctx.set_prior(np.zeros(k), np.eye(k) * 100.0, 1.0, 0.02)
+    T = 2000
+    ctx.gibbs_run(1, 200, seeds=[1])
+    out, st = ctx.gibbs_run(1, T, seeds=[1])
+    buf = (C.c_longlong * 8)()
+    lib.bmc_dev_get_stamps(ctx._h, buf)
+    cyc = np.array(list(buf), float) / T
+    print(f"{name}: G={st['groups_per_chain']} W={st['waves_per_group']} res={st['residency']} us/iter={st['loop_ms']*1e3/T:.2f} ticks/iter={cyc.sum():.0f}")
+    print("   " + "  ".join(f"{n_}:{c:.0f}" for n_, c in zip(names, cyc)))

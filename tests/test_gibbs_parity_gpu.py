@@ -310,3 +310,66 @@ def test_full_size_c2_properties():
     w = posterior_summary(pooled, Vt_hat)["weights_mean"]
     assert abs(w.sum() - 1.0) < 1e-9
     assert abs(pooled[:, -1].mean() - 0.1) < 0.005
+
+
+def test_c_abi_leading_dimensions_and_device_inputs():
+    """Straight through the C ABI: padded leading dimensions in both layouts, float32 storage,
+    and device-resident inputs (bmc_set_problem_device) must all describe the same problem."""
+    import ctypes as C
+    import torch
+    from pybmc_amd import _lib
+    ctx = gpu_ctx()
+    lib = _lib.load_library()
+    rng = np.random.default_rng(11)
+    n, k = 777, 6
+    X = rng.standard_normal((n, k))
+    y = rng.standard_normal(n)
+    ctx.set_problem(y, X)
+    want = ctx.gram()
+    # row-major with ldx = k + 3, col-major with ldx = n + 5
+    Xr = np.zeros((n, k + 3)); Xr[:, :k] = X
+    Xc = np.zeros((k, n + 5)); Xc[:, :n] = X.T
+    for buf, ldx, layout in ((Xr, k + 3, _lib.BMC_ROW_MAJOR), (Xc, n + 5, _lib.BMC_COL_MAJOR)):
+        rc = lib.bmc_set_problem(ctx._h, buf.ctypes.data_as(C.c_void_p), n, k, ldx, layout,
+                                 y.ctypes.data_as(C.c_void_p), _lib.BMC_F64)
+        assert rc == 0
+        ctx.n, ctx.k = n, k
+        assert np.array_equal(ctx.gram(), want)
+    # device-resident inputs (a torch tensor's storage), both layouts
+    for arr, ldx, layout in ((X, k, _lib.BMC_ROW_MAJOR), (np.ascontiguousarray(X.T), n, _lib.BMC_COL_MAJOR)):
+        tx = torch.from_numpy(arr).cuda()
+        ty = torch.from_numpy(y).cuda()
+        torch.cuda.synchronize()
+        ctx.set_problem_device(tx.data_ptr(), n, k, ldx, layout, ty.data_ptr())
+        assert np.array_equal(ctx.gram(), want)
+    # bad leading dimension / NULL pointers -> BMC_EINVAL, not a crash
+    assert lib.bmc_set_problem(ctx._h, Xr.ctypes.data_as(C.c_void_p), n, k, k - 1, 0,
+                               y.ctypes.data_as(C.c_void_p), 0) == _lib.BMC_EINVAL
+    assert lib.bmc_set_problem(ctx._h, None, n, k, k, 0, y.ctypes.data_as(C.c_void_p), 0) == _lib.BMC_EINVAL
+    assert lib.bmc_set_problem(ctx._h, Xr.ctypes.data_as(C.c_void_p), n, 300, 300, 0,
+                               y.ctypes.data_as(C.c_void_p), 0) == _lib.BMC_EINVAL
+    # float32 storage sees the float32-rounded matrix
+    ctx.set_problem(y, X, dtype=np.float32)
+    X32, y32 = X.astype(np.float32).astype(float), y.astype(np.float32).astype(float)
+    Xa = np.column_stack([X32, y32])
+    assert np.abs(ctx.gram() - Xa.T @ Xa).max() < 1e-10 * np.abs(Xa.T @ Xa).max()
+
+
+def test_residual_kernel_properties_at_full_size():
+    """Size-independent properties of the residual-reduction kernel at the C4 shape
+    (N = 200000, K = 64, float32 storage): rss(0) = y'y, scaling, and the Gram identity
+    rss(b) = y'y - 2 b'X'y + b'X'X b (all against the kernel's own MFMA Gram)."""
+    ctx = gpu_ctx()
+    rng = np.random.Generator(np.random.PCG64(4))
+    n, k = 200000, 64
+    X = np.asfortranarray(rng.standard_normal((n, k), dtype=np.float32))
+    y = rng.standard_normal(n, dtype=np.float32)
+    ctx.set_problem(y, X, dtype=np.float32)
+    G = ctx.gram()
+    A, c, yty = G[:k, :k], G[:k, k], G[k, k]
+    assert abs(ctx.residual_rss(np.zeros(k))[0] - yty) <= 1e-12 * yty
+    B = rng.standard_normal((5, k)) * 0.1
+    got = ctx.residual_rss(B)
+    want = np.array([yty - 2 * b @ c + b @ A @ b for b in B])
+    assert np.abs(got - want).max() < 1e-10 * yty
+    assert np.abs(np.linalg.eigvalsh(A)).min() > 0 and np.allclose(A, A.T, rtol=0, atol=0)
