@@ -19,7 +19,6 @@ using namespace bmc;
 namespace {
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
-constexpr int MAX_GROUPS_PER_LAUNCH = 256;  // one resident workgroup per CU
 
 struct DevBuf {
     void* p = nullptr;
@@ -113,7 +112,7 @@ int choose_vec(int64_t n, int32_t k, int f32) {
     // register residency: the narrowest panel that lets every panel have its own wave (more
     // waves = shorter serial FMA phase); two rows per lane (wider reads for the streaming
     // kernels that share the layout) once one row per lane would need two panels per wave
-    const int64_t waves_chip = 256 * 8;
+    const int64_t waves_chip = 256 * 8;   // sized for the full chip; geometry re-checks the fit
     if (gibbs_reg_capacity(k, f32, 1) && (n + 63) / 64 <= waves_chip) return 1;
     if (gibbs_reg_capacity(k, f32, 2) && (n + 127) / 128 <= waves_chip) return 2;
     for (int ppw : {2, 4})
@@ -209,11 +208,28 @@ struct Geometry {
 };
 
 constexpr int RES_AUTO = 0, RES_REG = 1, RES_STREAM = 3;  // 2 = LDS
-constexpr int XCD_COUNT = 8, CU_PER_XCD = 32;
+// Chip shape from the device properties (MI355X in SPX mode: 256 CUs = 8 XCDs x 32; a
+// partitioned device exposes fewer CUs, and the co-residency bound must follow it).
+struct Chip {
+    int groups_max;   // one resident workgroup per CU
+    int xcds;         // slots: blocks b and b + xcds share an XCD (observed round-robin)
+    int cu_per_xcd;
+};
+Chip chip_of(const bmc_ctx* c) {
+    Chip ch;
+    ch.groups_max = c->n_cu > 0 ? c->n_cu : 256;
+    if (ch.groups_max > 256) ch.groups_max = 256;   // the gather holds 2 x 256 granules
+    ch.xcds = ch.groups_max >= 64 ? ch.groups_max / 32 : 1;
+    ch.cu_per_xcd = ch.groups_max / ch.xcds;
+    return ch;
+}
 
 // Pick the launch geometry.  Preference order: row panels in VGPRs with each chain on
 // one XCD (8 slots x <= 32 groups), then panels pinned in LDS, then streaming.
 Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
+    const Chip chip = chip_of(c);
+    const int MAX_GROUPS_PER_LAUNCH = chip.groups_max, XCD_COUNT = chip.xcds,
+              CU_PER_XCD = chip.cu_per_xcd;
     const int RP = 64 * c->vec;
     const size_t es = c->f32 ? 4 : 8;
     const size_t panel_bytes = (size_t)(c->k + 1) * RP * es;

@@ -419,13 +419,22 @@ __global__ __launch_bounds__(256) void residual_rss_kernel(
         ticket = __hip_atomic_fetch_add(ticket_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != gridDim.x - 1) return;
-    const int ngroups = gridDim.x;
+    const int ngroups = gridDim.x;   // <= 1024: at most 16 partials per lane
+    const unsigned long long* pw = reinterpret_cast<const unsigned long long*>(partial);
     for (int b = 0; b < nb; ++b) {
+        // all loads of a coefficient vector in flight together (one memory round trip),
+        // then a fixed-order sum
+        unsigned long long w[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int gi = lane + 64 * q;
+            w[q] = gi < ngroups ? __hip_atomic_load(pw + (size_t)gi * NB + b, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT)
+                                : 0ull;
+        }
         double t = 0.0;
-        for (int gi = lane; gi < ngroups; gi += 64)
-            t += __longlong_as_double((long long)__hip_atomic_load(
-                reinterpret_cast<const unsigned long long*>(partial) + (size_t)gi * NB + b,
-                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += __longlong_as_double((long long)w[q]);
         t = wave_sum(t);
         if (lane == 0) rss[b] = t;
     }
