@@ -10,6 +10,7 @@ from __future__ import annotations
 import numpy as np
 import pandas as pd
 
+from .data import apply_domain_filters
 from .inference_utils import USVt_hat_extraction, gibbs_sampler, gibbs_sampler_simplex
 from .sampling_utils import predictive_coverage, rndm_m_random_calculator
 
@@ -204,19 +205,9 @@ class BayesianModelCombination:
         """Coverage of the credible intervals at 0,5,...,100 %
         (reference bmc.py:339-376; same filter semantics)."""
         self._require_trained()
-        df = self.data_dict[self.current_property]
-        if domain_filter:
-            for col, cond in domain_filter.items():
-                if col == "multi" and callable(cond):
-                    df = df[df.apply(cond, axis=1)]
-                elif callable(cond):
-                    df = df[cond(df[col])]
-                elif isinstance(cond, tuple) and len(cond) == 2:
-                    df = df[df[col].between(*cond)]
-                elif isinstance(cond, list):
-                    df = df[df[col].isin(cond)]
-                else:
-                    df = df[df[col] == cond]
+        # tuple ranges use Series.between in the reference (bmc.py:360): inclusive, like the
+        # explicit comparisons of the shared helper
+        df = apply_domain_filters(self.data_dict[self.current_property], domain_filter)
         return predictive_coverage(np.arange(0, 101, 5), df[self.models].to_numpy(), self.samples,
                                    self.Vt_hat, df[self.truth_column_name].to_numpy(),
                                    device=self.device)
