@@ -373,3 +373,29 @@ def test_residual_kernel_properties_at_full_size():
     want = np.array([yty - 2 * b @ c + b @ A @ b for b in B])
     assert np.abs(got - want).max() < 1e-10 * yty
     assert np.abs(np.linalg.eigvalsh(A)).min() > 0 and np.allclose(A, A.T, rtol=0, atol=0)
+
+
+def test_t2_long_chain_at_c2_size():
+    """5000 iterations at N = 10000, K = 32 (ten times the committed golden prefix): the oracle
+    chain (numpy streams, computed here) replayed through the HIP loop; rounding differences must
+    not accumulate (the chain map contracts) -- north-star bar 1e-6 on the summaries."""
+    ctx = gpu_ctx()
+    p = synth_problem(10000, 33, 32, seed=0)
+    y, X, prior = p["y"], p["X"], p["prior"]
+    T = 5000
+    st = O.chain_setup(y, X, prior)
+    Z, G = O.reference_streams(101, 102, T, 32, O.gamma_shape(st))
+    ref, trace = O.gibbs_replay(y, X, T, prior, Z, G, return_sigma2=True)
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    W, lam, _ = ctx.basis()
+    xi = O.innovations_in_basis(st, y, X, ref, W, lam, trace)
+    out, stats = ctx.gibbs_run(1, T, xi=xi[None], g=G[None])
+    assert stats["residency"] == 1 and stats["xcd_local_chains"] in (0, 1)
+    err = np.abs(out[0] - ref)
+    assert err.max() < 1e-11
+    assert err[-500:].max() <= 10 * max(err[:500].max(), 1e-15)      # no drift
+    Vt_hat = p["Vt"] / p["S_hat"][:, None]
+    a, b = posterior_summary(out[0], Vt_hat), posterior_summary(ref, Vt_hat)
+    for key in b:
+        assert rel(a[key], b[key]) < REL_BAR, key
