@@ -50,7 +50,8 @@ typedef struct {
     int32_t residency;        /* 0 auto, 1 registers, 2 LDS, 3 stream from HBM */
     int32_t panels_per_wave;  /* register residency: 1, 2 or 4                 */
     int32_t force_agent_scope;/* 1 = never use the XCD-local (L2) exchange     */
-    int32_t chains_per_pass;  /* reserved                                      */
+    int32_t chains_per_pass;  /* streamed/LDS panels: chains served by one read of X;
+                                 0 auto (up to 8), 1 off, 2/4/8 cap             */
 } bmc_tuning;
 
 /* Filled by bmc_gibbs_run*.  Times are HIP-event times on the context's stream. */

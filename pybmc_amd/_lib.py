@@ -179,10 +179,11 @@ class Context:
         self._check(self._lib.bmc_set_stream(self._h, _P(hip_stream_ptr or 0)))
 
     def set_tuning(self, groups_per_chain=0, waves_per_group=0, residency=0, panels_per_wave=0,
-                   force_agent_scope=0):
-        """residency: 0 auto, 1 registers, 2 LDS, 3 stream from HBM."""
+                   force_agent_scope=0, chains_per_pass=0):
+        """residency: 0 auto, 1 registers, 2 LDS, 3 stream from HBM; chains_per_pass: 0 auto,
+        1 off, 2/4/8 cap (streamed or LDS-pinned panels only)."""
         t = Tuning(groups_per_chain, waves_per_group, residency, panels_per_wave,
-                   force_agent_scope, 0)
+                   force_agent_scope, chains_per_pass)
         self._check(self._lib.bmc_set_tuning(self._h, C.byref(t)))
 
     # -- problem / prior ---------------------------------------------------------

@@ -233,7 +233,8 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
     const int RP = 64 * c->vec;
     const size_t es = c->f32 ? 4 : 8;
     const size_t panel_bytes = (size_t)(c->k + 1) * RP * es;
-    const size_t fixed = (size_t)((c->k + 63) / 64 * 64) * 8 * 4 + 20 * 8 + 64;
+    // u slices for up to 8 chains per pass + partial sums + control words + alignment slack
+    const size_t fixed = (size_t)((c->k + 63) / 64 * 64) * 8 * 8 + 72 * 8 + 64;
     const int NP = c->npanels;
     const bmc_tuning& tu = c->tune;
     auto lds_fits = [&](int G) {
@@ -342,7 +343,9 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     }
     const Geometry geo = choose_geometry(c, n_chains);
     const int gran_stride = ((2 * geo.G + 31) / 32) * 32;
-    if ((rc = ensure(c, c->gran, (size_t)geo.chains_per_launch * 3 * gran_stride * 8))) return rc;
+    if ((rc = ensure(c, c->gran, (size_t)(geo.chains_per_launch > 8 ? geo.chains_per_launch : 8) * 3 *
+                                     gran_stride * 8)))
+        return rc;
     if ((rc = ensure(c, c->status, C * sizeof(int32_t)))) return rc;
     if ((rc = ensure(c, c->placement, C * sizeof(int32_t)))) return rc;
     HIPCHK(c, hipMemsetAsync(c->placement.p, 0, C * sizeof(int32_t), c->stream));
@@ -388,10 +391,23 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 8 * sizeof(long long), c->stream));
     a.dbg = (long long*)c->dbg.p;
 #endif
-    int launches = 0;
-    for (int c0 = 0; iters > 0 && c0 < n_chains; c0 += geo.chains_per_launch) {
-        const int m = n_chains - c0 < geo.chains_per_launch ? n_chains - c0 : geo.chains_per_launch;
+    // chains per pass: when the panels are NOT register-resident one read of X can serve up to
+    // 8 chains (one leader wave per chain); 0 = automatic, 1 = off
+    int cpp_max = 1;
+    if (geo.mode != 0 && n_chains > 1 && c->tune.chains_per_pass != 1) {
+        cpp_max = geo.waves >= 8 ? 8 : geo.waves >= 4 ? 4 : geo.waves >= 2 ? 2 : 1;
+        if (c->tune.chains_per_pass > 1 && c->tune.chains_per_pass < cpp_max)
+            cpp_max = c->tune.chains_per_pass >= 4 ? 4 : 2;
+    }
+    int launches = 0, cpp_used = 1;
+    for (int c0 = 0; iters > 0 && c0 < n_chains;) {
+        const int left = n_chains - c0;
+        int cpp = 1;
+        while (cpp * 2 <= left && cpp * 2 <= cpp_max) cpp *= 2;
+        const int m = cpp > 1 ? cpp : (left < geo.chains_per_launch ? left : geo.chains_per_launch);
         a.n_chains = m;
+        a.chains_per_pass = cpp;
+        if (cpp > cpp_used) cpp_used = cpp;
         a.xi = (const double*)c->xi.p + (size_t)c0 * T * K;
         a.gam = (const double*)c->gam.p + (size_t)c0 * T;
         a.uout = (double*)c->uout.p + (size_t)c0 * T * (K + 1);
@@ -401,6 +417,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         if (gibbs_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
         HIPCHK(c, launch_gibbs(a, c->stream));
         ++launches;
+        c0 += m;
     }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (iters > 0)
@@ -428,12 +445,13 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         stats->launches = launches;
         stats->groups_per_chain = geo.G;
         stats->waves_per_group = geo.waves;
-        stats->chains_per_pass = 1;
+        stats->chains_per_pass = cpp_used;
         stats->residency = geo.mode + 1;
         stats->xcd_local_chains = 0;
         for (size_t i = 0; i < C; ++i) stats->xcd_local_chains += place[i] ? 1 : 0;
         stats->bytes_per_pass = ((int64_t)c->n * K + c->n) * (c->f32 ? 4 : 8);
-        stats->passes = (int64_t)n_chains * iters;
+        // a pass that serves several chains counts once
+        stats->passes = cpp_used > 1 ? (int64_t)launches * iters : (int64_t)n_chains * iters;
     }
     for (size_t i = 0; i < C; ++i)
         if (st[i] != 0)
@@ -519,9 +537,11 @@ int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
     if (t->groups_per_chain < 0 || t->groups_per_chain > 256 || t->waves_per_group < 0 ||
         t->waves_per_group > 8 || t->residency < 0 || t->residency > 3 ||
         (t->panels_per_wave != 0 && t->panels_per_wave != 1 && t->panels_per_wave != 2 &&
-         t->panels_per_wave != 4))
+         t->panels_per_wave != 4) ||
+        (t->chains_per_pass != 0 && t->chains_per_pass != 1 && t->chains_per_pass != 2 &&
+         t->chains_per_pass != 4 && t->chains_per_pass != 8))
         return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..8, residency 0..3, "
-                                   "panels_per_wave 0/1/2/4)");
+                                   "panels_per_wave 0/1/2/4, chains_per_pass 0/1/2/4/8)");
     c->tune = *t;
     return BMC_OK;
 }

@@ -19,12 +19,12 @@ struct LdsPlan {
 // u: K doubles zero-padded to a multiple of 64 (MODE_REG reads KMAX of them);
 // aux: kernel-specific doubles (the simplex kernel keeps Vt_hat there when it fits).
 __host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bool lds_resident,
-                                            int aux_doubles = 0) {
+                                            int aux_doubles = 0, int u_slices = 1) {
     LdsPlan L;
-    const size_t kp = (size_t)((K + 63) & ~63) * sizeof(double);
+    const size_t kp = (size_t)((K + 63) & ~63) * sizeof(double) * (size_t)u_slices;
     size_t o = 0;
     L.u = o;   o += kp;
-    L.red = o; o += 16 * sizeof(double);
+    L.red = o; o += 64 * sizeof(double);   // [chains per pass <= 8][waves <= 8]
     L.ctl = o; o += 8 * sizeof(double);
     L.aux = o; o += (size_t)((aux_doubles + 1) & ~1) * sizeof(double);
     L.y = o;
@@ -314,6 +314,93 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
         } else {
             granule_put<false>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));
             granule_put<false>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(s));
+        }
+    }
+    gu64 x[MAX_GRAN_REG];
+    ok = granule_gather(gp, 2 * G, epoch, lane, x);
+    return ok ? granule_sum(x, 2 * G, lane) : 0.0;
+}
+
+// ---- several chains per pass (streaming / LDS residency) ---------------------------------
+// One read of a panel column feeds CPP chains' accumulators; per chain the operation order
+// is exactly that of panel_rss, so a chain's bits do not depend on how many chains share
+// the pass.
+template <typename T, int VEC, int CPP>
+__device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const T* __restrict__ yp,
+                                                const double* __restrict__ u, int kpad, int K,
+                                                double (&s)[CPP]) {
+    constexpr int RP = 64 * VEC;
+    constexpr int UN = 16;
+    double a0[CPP][VEC], a1[CPP][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const double yv = (double)yp[v];
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) { a0[c][v] = yv; a1[c][v] = 0.0; }
+    }
+    int j = 0;
+    for (; j + UN <= K; j += UN) {
+        T x[UN][VEC];
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[q][v] = xp[(size_t)(j + q) * RP + v];
+#pragma unroll
+        for (int q = 0; q < UN; q += 2)
+#pragma unroll
+            for (int c = 0; c < CPP; ++c) {
+                const double u0 = u[c * kpad + j + q], u1 = u[c * kpad + j + q + 1];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    a0[c][v] = fma(-(double)x[q][v], u0, a0[c][v]);
+                    a1[c][v] = fma(-(double)x[q + 1][v], u1, a1[c][v]);
+                }
+            }
+    }
+    for (; j < K; ++j)
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) {
+            const double u0 = u[c * kpad + j];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) a0[c][v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[c][v]);
+        }
+#pragma unroll
+    for (int c = 0; c < CPP; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const double r = a0[c][v] + a1[c][v];
+            t = fma(r, r, t);
+        }
+        s[c] += t;
+    }
+}
+
+// All-reduce of CPP lane partials: wave c < CPP leads chain c (sums the waves' partials of
+// its chain, publishes and gathers on that chain's granules).  Every wave calls it.
+template <int CPP>
+__device__ __forceinline__ double group_allreduce_multi(const double (&s)[CPP], double* red,
+                                                        gu64* gp_chain0, size_t chain_stride,
+                                                        int G, int g, int wave, int nw, int lane,
+                                                        unsigned epoch, bool local, bool& ok) {
+#pragma unroll
+    for (int c = 0; c < CPP; ++c) {
+        const double t = wave_sum(s[c]);
+        if (lane == 0) red[c * 8 + wave] = t;
+    }
+    __syncthreads();
+    ok = true;
+    if (wave >= CPP) return 0.0;
+    double t = red[wave * 8];
+    for (int w = 1; w < nw; ++w) t += red[wave * 8 + w];
+    gu64* gp = gp_chain0 + (size_t)wave * chain_stride;
+    if (lane == 0) {
+        if (local) {
+            granule_put<true>(gp + 2 * g, epoch, (unsigned)__double2hiint(t));
+            granule_put<true>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(t));
+        } else {
+            granule_put<false>(gp + 2 * g, epoch, (unsigned)__double2hiint(t));
+            granule_put<false>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(t));
         }
     }
     gu64 x[MAX_GRAN_REG];

@@ -187,6 +187,140 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
 }
 
 // ======================================================================================
+// Several chains per pass.  When the panels are streamed (or LDS-pinned), one read of X
+// serves CPP chains: wave c < CPP is the leader of chain c (its u, its granules, its sigma2
+// state, and -- in group 0 -- its recorded draws); all waves accumulate CPP partial sums per
+// panel column.  Arithmetic per chain is that of gibbs_loop_kernel, operation for operation.
+// ======================================================================================
+template <typename T, int VEC, int MODE, int CPP>
+__global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
+    constexpr int RP = 64 * VEC;
+    static_assert(MODE != MODE_REG, "several chains per pass: LDS or streaming residency");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = a.P.k, G = a.G;
+    const int g = blockIdx.x;             // one bundle of CPP chains per launch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = blockDim.x >> 6;
+    const int64_t T_it = a.iters;
+
+    const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, MODE == MODE_LDS, 0, CPP);
+    double* u_lds = reinterpret_cast<double*>(smem + L.u);   // [CPP][kpad]
+    double* red = reinterpret_cast<double*>(smem + L.red);   // [CPP][8]
+    double* ctl = reinterpret_cast<double*>(smem + L.ctl);   // [1] abort, [2] local
+    const int kpad = (K + 63) & ~63;
+    for (int j = tid; j < kpad * CPP; j += blockDim.x) u_lds[j] = 0.0;
+    if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; }
+
+    PanelStore<T, VEC, MODE, 0, 0> store;
+    store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y));
+
+    const size_t chain_stride = (size_t)3 * a.gran_stride;
+    if (wave == 0) {
+        const int place = detect_placement(a.gran + 2 * a.gran_stride, G, g, lane);
+        if (lane == 0) {
+            if (place < 0) { ctl[1] = 1.0; a.status[0] = 1; }
+            ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    const bool local = ctl[2] != 0.0;
+    if (g == 0 && tid < CPP) a.placement[tid] = local ? 1 : 0;
+
+    const bool leader = wave < CPP;
+    const int chain = leader ? wave : 0;
+    const double* xi = a.xi + (int64_t)chain * T_it * K;
+    const double* gam = a.gam + (int64_t)chain * T_it;
+    double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
+    double* u_mine = u_lds + (size_t)chain * kpad;
+
+    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
+    double xi_next[MAX_KCH], lam_r[MAX_KCH], c1_r[MAX_KCH], c2_r[MAX_KCH];
+    double gam_next = 0.0;
+    if (leader) {
+#pragma unroll
+        for (int ch = 0; ch < MAX_KCH; ++ch) {
+            const int j = ch * 64 + lane;
+            xi_next[ch] = (j < K && T_it > 0) ? xi[j] : 0.0;
+            lam_r[ch] = j < K ? a.lam[j] : 0.0;
+            c1_r[ch] = j < K ? a.c1[j] : 0.0;
+            c2_r[ch] = j < K ? a.c2[j] : 0.0;
+        }
+        if (T_it > 0) gam_next = gam[0];
+    }
+
+    for (int64_t t = 0; t < T_it; ++t) {
+        const unsigned epoch = (unsigned)(t + 1);
+        double u_rec[MAX_KCH];
+        const double sp_rec = sp_eff, g_rec = g_eff;   // sigma2 of the previous row
+        if (leader) {
+#pragma unroll
+            for (int ch = 0; ch < MAX_KCH; ++ch) {
+                const int j = ch * 64 + lane;
+                u_rec[ch] = 0.0;
+                if (ch * 64 < K && j < K) {
+                    const double D = fma(lam_r[ch], g_eff, sp_eff);
+                    const double r = rsqrt(D);
+                    const double m = fma(c2_r[ch], g_eff, c1_r[ch] * sp_eff);
+                    u_rec[ch] = fma(r * r, m, (sq_sp * r) * xi_next[ch]);
+                    u_mine[j] = u_rec[ch];
+                }
+            }
+        }
+        __syncthreads();  // B1
+        if (ctl[1] != 0.0) break;
+        const double gam_t = gam_next;
+        if (leader && t + 1 < T_it) {
+#pragma unroll
+            for (int ch = 0; ch < MAX_KCH; ++ch) {
+                const int j = ch * 64 + lane;
+                if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
+            }
+            gam_next = gam[t + 1];
+        }
+        double s[CPP];
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) s[c] = 0.0;
+        for (int q = store.wave; q < store.npl; q += store.nw) {
+            if constexpr (MODE == MODE_LDS) {
+                panel_rss_multi<T, VEC, CPP>(store.Xs + (size_t)q * K * RP + lane * VEC,
+                                             store.ys + q * RP + lane * VEC, u_lds, kpad, K, s);
+            } else {
+                const int64_t p = g + (int64_t)q * G;
+                panel_rss_multi<T, VEC, CPP>(store.Xg + p * (int64_t)K * RP + lane * VEC,
+                                             store.yg + p * RP + lane * VEC, u_lds, kpad, K, s);
+            }
+        }
+        bool got;
+        const double rss = group_allreduce_multi<CPP>(s, red, a.gran + (size_t)(t & 1) * a.gran_stride,
+                                                      chain_stride, G, g, wave, nw, lane, epoch,
+                                                      local, got);
+        if (leader) {
+            if (g == 0) {   // this chain's row t, and sigma of its previous row
+#pragma unroll
+                for (int ch = 0; ch < MAX_KCH; ++ch) {
+                    const int j = ch * 64 + lane;
+                    if (ch * 64 < K && j < K) uout[t * (K + 1) + j] = u_rec[ch];
+                }
+                if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
+            }
+            if (!got) {
+                if (lane == 0) { ctl[1] = 1.0; a.status[chain] = 1; }
+            } else {
+                const double scale_post = (a.nu0_s20 + rss) * 0.5;
+                const bool floor_hit = scale_post < 1e-6 * gam_t;
+                sp_eff = floor_hit ? 1e-6 : scale_post;
+                g_eff = floor_hit ? 1.0 : gam_t;
+                sq_sp = sqrt(sp_eff);
+            }
+        }
+    }
+    __syncthreads();
+    if (leader && g == 0 && lane == 0 && T_it > 0 && ctl[1] == 0.0)
+        uout[(T_it - 1) * (K + 1) + K] = sqrt(sp_eff / g_eff);
+}
+
+// ======================================================================================
 // Simplex-constrained sampler (reference pybmc/inference_utils.py:78-144): random-walk
 // Metropolis on beta with the weights beta Vt_hat + 1/Km kept on the simplex, Gibbs step
 // for sigma2.  Same machinery: the proposal's rss is the group all-reduce above.  A
@@ -346,7 +480,8 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
 }
 
 size_t gibbs_lds_bytes(const GibbsArgs& a) {
-    return lds_plan(a.P.k, a.P.f32 ? 4 : 8, 64 * a.P.vec, a.panels_per_group, a.mode == MODE_LDS).total;
+    return lds_plan(a.P.k, a.P.f32 ? 4 : 8, 64 * a.P.vec, a.panels_per_group, a.mode == MODE_LDS, 0,
+                    a.chains_per_pass > 1 ? a.chains_per_pass : 1).total;
 }
 size_t simplex_lds_bytes(const SimplexArgs& a) {
     return lds_plan(a.P.k, a.P.f32 ? 4 : 8, 64 * a.P.vec, a.panels_per_group, a.mode == MODE_LDS,
@@ -437,7 +572,52 @@ static bool geometry_ok(const Args& a) {
            a.waves <= 8 && a.nslot >= 1 && a.nslot <= 256;
 }
 
+template <typename T, int VEC, int MODE>
+static hipError_t launch_multi_cpp(const GibbsArgs& a, hipStream_t s) {
+    const size_t lds = gibbs_lds_bytes(a);
+#define BMC_MULTI(C)                                                                          \
+    do {                                                                                      \
+        hipError_t e = hipFuncSetAttribute((const void*)gibbs_multi_kernel<T, VEC, MODE, C>,  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                           (int)lds);                                         \
+        if (e != hipSuccess) return e;                                                        \
+        hipLaunchKernelGGL((gibbs_multi_kernel<T, VEC, MODE, C>), dim3(a.G), dim3(64 * a.waves), \
+                           lds, s, a);                                                        \
+        return hipGetLastError();                                                             \
+    } while (0)
+    switch (a.chains_per_pass) {
+        case 2: BMC_MULTI(2);
+        case 4: BMC_MULTI(4);
+        case 8: BMC_MULTI(8);
+    }
+#undef BMC_MULTI
+    return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t launch_multi_t(const GibbsArgs& a, hipStream_t s) {
+#define BMC_MM(V)                                                         \
+    (a.mode == MODE_LDS ? launch_multi_cpp<T, V, MODE_LDS>(a, s)           \
+                        : launch_multi_cpp<T, V, MODE_STREAM>(a, s))
+    switch (a.P.vec) {
+        case 1: return BMC_MM(1);
+        case 2: return BMC_MM(2);
+        case 4:
+            if constexpr (sizeof(T) == 4) return BMC_MM(4);
+            break;
+    }
+#undef BMC_MM
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
+    if (a.chains_per_pass > 1) {
+        // one bundle of chains_per_pass chains; needs a leader wave per chain
+        if (!geometry_ok(a) || a.mode == MODE_REG || a.waves < a.chains_per_pass ||
+            a.n_chains != a.chains_per_pass)
+            return hipErrorInvalidValue;
+        return a.P.f32 ? launch_multi_t<float>(a, s) : launch_multi_t<double>(a, s);
+    }
     if (!geometry_ok(a) || a.n_chains < 1 || a.n_chains > a.nslot) return hipErrorInvalidValue;
     return a.P.f32 ? launch_t<GibbsTag, GibbsArgs, float>(a, s)
                    : launch_t<GibbsTag, GibbsArgs, double>(a, s);

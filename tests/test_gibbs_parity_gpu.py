@@ -399,3 +399,39 @@ def test_t2_long_chain_at_c2_size():
     a, b = posterior_summary(out[0], Vt_hat), posterior_summary(ref, Vt_hat)
     for key in b:
         assert rel(a[key], b[key]) < REL_BAR, key
+
+
+@pytest.mark.parametrize("n,k,res,nch", [(3000, 8, 3, 8), (3000, 8, 2, 5), (700, 130, 3, 3),
+                                         (5000, 33, 3, 8)])
+def test_several_chains_per_pass(n, k, res, nch):
+    """Streamed / LDS-pinned panels: one read of X serves up to 8 chains (gibbs_multi_kernel).
+    A chain must not notice how many chains share its pass."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(n + k)
+    X = rng.standard_normal((n, k)) / np.sqrt(n)
+    y = X @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)
+    prior = (np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    T = 300
+    seeds = np.arange(nch) + 3
+    ctx.set_tuning(residency=res, chains_per_pass=1)
+    solo, st1 = ctx.gibbs_run(nch, T, seeds=seeds)
+    assert st1["chains_per_pass"] == 1
+    ctx.set_tuning(residency=res, chains_per_pass=0)
+    shared, st = ctx.gibbs_run(nch, T, seeds=seeds)
+    ctx.set_tuning()
+    assert st["residency"] == res and st["chains_per_pass"] in (2, 4, 8)
+    assert np.abs(shared - solo).max() < 1e-11 * max(1.0, np.abs(solo).max())
+    # and the replay tier through the shared pass: the oracle chain in every slot
+    st_o = O.chain_setup(y, X, prior)
+    Z, G = O.reference_streams(5, 6, 100, k, O.gamma_shape(st_o))
+    ref, trace = O.gibbs_replay(y, X, 100, prior, Z, G, return_sigma2=True)
+    W, lam, _ = ctx.basis()
+    xi = O.innovations_in_basis(st_o, y, X, ref, W, lam, trace)
+    ctx.set_tuning(residency=res)
+    out, st = ctx.gibbs_run(4, 100, xi=np.repeat(xi[None], 4, 0), g=np.repeat(G[None], 4, 0))
+    ctx.set_tuning()
+    assert st["chains_per_pass"] in (2, 4)
+    for c in range(4):
+        assert np.abs(out[c] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
