@@ -297,6 +297,10 @@ struct PanelStore {
 // chain-wide sum (identical bits in every group); `ok` is false when the spin expired.
 // Other waves get an unspecified value.  Order of summation is fixed: DPP butterfly inside a
 // wave, waves in index order, groups in index order.
+// SINGLE = the chain lives in ONE workgroup (G == 1): nothing to exchange, the group total is
+// the chain total.  A template parameter, not a run-time test, so that the multi-group code is
+// byte-for-byte what it was (a run-time `if (G == 1)` cost the C2 path 4 %).
+template <bool SINGLE = false>
 __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
                                                   int wave, int nw, int lane, unsigned epoch,
                                                   bool local, bool& ok) {
@@ -307,6 +311,7 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
     if (wave != 0) return 0.0;
     s = red[0];
     for (int w = 1; w < nw; ++w) s += red[w];
+    if constexpr (SINGLE) return s;
     if (lane == 0) {
         if (local) {
             granule_put<true>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));

@@ -40,7 +40,7 @@
 
 namespace bmc {
 
-template <typename T, int VEC, int MODE, int KMAX, int PPW>
+template <typename T, int VEC, int MODE, int KMAX, int PPW, bool SINGLE = false>
 __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,16 +69,18 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
 
     // ---- where do this chain's groups really run? -------------------------------------
     gu64* gr = a.gran + (size_t)chain * 3 * a.gran_stride;
-    if (wave == 0) {
-        const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane);
-        if (lane == 0) {
-            if (place < 0) { ctl[1] = 1.0; a.status[chain] = 1; }
-            ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
+    if constexpr (!SINGLE) {
+        if (wave == 0) {
+            const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane);
+            if (lane == 0) {
+                if (place < 0) { ctl[1] = 1.0; a.status[chain] = 1; }
+                ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
+            }
         }
     }
     __syncthreads();
     const bool local = ctl[2] != 0.0;
-    if (g == 0 && tid == 0) a.placement[chain] = local ? 1 : 0;
+    if (g == 0 && tid == 0) a.placement[chain] = (local || SINGLE) ? 1 : 0;
 
     const double* xi = a.xi + (int64_t)chain * T_it * K;
     const double* gam = a.gam + (int64_t)chain * T_it;
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
         const double part = store.partial_rss(u_lds);
         STAMP(2);
         bool got;
-        const double rss = group_allreduce(part, red, gr + (size_t)(t & 1) * a.gran_stride, G, g,
-                                           wave, nw, lane, epoch, local, got);
+        const double rss = group_allreduce<SINGLE>(part, red, gr + (size_t)(t & 1) * a.gran_stride,
+                                                   G, g, wave, nw, lane, epoch, local, got);
         STAMP(5);
         if (recorder) {
             // row t = [u_t, .]; sigma of the PREVIOUS row (its sp, g were final at B1)
@@ -495,6 +497,17 @@ struct SimplexTag {};
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
+    if constexpr (MODE == MODE_REG) {
+        if (a.G == 1) {  // the chain fits one workgroup: no exchange code at all
+            hipError_t e = hipFuncSetAttribute(
+                (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>),
+                               dim3(a.nslot * a.G), dim3(64 * a.waves), lds, s, a);
+            return hipGetLastError();
+        }
+    }
     hipError_t e = hipFuncSetAttribute((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -569,7 +582,7 @@ int gibbs_reg_capacity(int k, int f32, int rows_per_lane) {
 template <typename Args>
 static bool geometry_ok(const Args& a) {
     return a.P.k <= 64 * MAX_KCH && a.G <= 32 * MAX_GRAN_REG && a.G >= 1 && a.waves >= 1 &&
-           a.waves <= 8 && a.nslot >= 1 && a.nslot <= 256;
+           a.waves <= 8 && a.nslot >= 1 && a.nslot <= 2048;
 }
 
 template <typename T, int VEC, int MODE>

@@ -187,13 +187,32 @@ def test_chain_depends_on_its_seed_only():
 
 def test_more_chains_than_one_launch_holds():
     ctx = gpu_ctx()
-    p = synth_problem(2000, 6, 5, seed=4)
+    p = synth_problem(20000, 6, 5, seed=4)           # 313 panels: several groups per chain
     ctx.set_problem(p["y"], p["X"])
     ctx.set_prior(*p["prior"])
     out, stats = ctx.gibbs_run(19, 200, seeds=np.arange(19) + 1)
-    assert stats["launches"] >= 3 and np.isfinite(out).all()
+    assert stats["groups_per_chain"] > 1 and stats["launches"] >= 3 and np.isfinite(out).all()
     solo, _ = ctx.gibbs_run(1, 200, seeds=[19])
     assert np.abs(out[18] - solo[0]).max() < 1e-11
+
+
+def test_small_problem_runs_in_one_workgroup_per_chain():
+    """N <= a few thousand rows: the chain lives in ONE workgroup (no exchange, no co-residency
+    requirement), so hundreds of chains share a launch; results equal the multi-group kernel's."""
+    ctx = gpu_ctx()
+    p = synth_problem(629, 4, 3, seed=3)
+    ctx.set_problem(p["y"], p["X"])
+    ctx.set_prior(*p["prior"])
+    T = 400
+    seeds = np.arange(300) + 1
+    many, st = ctx.gibbs_run(300, T, seeds=seeds)
+    assert st["groups_per_chain"] == 1 and st["launches"] == 1 and st["residency"] == 1
+    ctx.set_tuning(groups_per_chain=10, waves_per_group=1)
+    multi, st2 = ctx.gibbs_run(3, T, seeds=seeds[[0, 150, 299]])
+    ctx.set_tuning()
+    assert st2["groups_per_chain"] == 10
+    for i, c in enumerate((0, 150, 299)):
+        assert np.abs(many[c] - multi[i]).max() < 1e-11
 
 
 # ---------------------------------------------------------------- edge cases
