@@ -418,10 +418,16 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     // 8 chains (one leader wave per chain); 0 = automatic, 1 = off
     int cpp_max = 1;
     if (geo.mode != 0 && n_chains > 1 && c->tune.chains_per_pass != 1) {
-        cpp_max = geo.waves >= 8 ? 8 : geo.waves >= 4 ? 4 : geo.waves >= 2 ? 2 : 1;
-        if (c->tune.chains_per_pass > 1 && c->tune.chains_per_pass < cpp_max)
-            cpp_max = c->tune.chains_per_pass >= 4 ? 4 : 2;
+        // every chain of a pass needs a leader wave: widen the workgroup if the panels alone
+        // would ask for fewer waves (the extra waves own no panel, they only lead a chain)
+        int want = n_chains >= 8 ? 8 : n_chains >= 4 ? 4 : 2;
+        if (c->tune.chains_per_pass > 1 && c->tune.chains_per_pass < want)
+            want = c->tune.chains_per_pass >= 4 ? 4 : 2;
+        if (a.waves < want && c->tune.waves_per_group <= 0) a.waves = want;
+        cpp_max = a.waves >= 8 ? 8 : a.waves >= 4 ? 4 : a.waves >= 2 ? 2 : 1;
+        if (cpp_max > want) cpp_max = want;
     }
+    const int waves_single = geo.waves;
     int launches = 0, cpp_used = 1;
     for (int c0 = 0; iters > 0 && c0 < n_chains;) {
         const int left = n_chains - c0;
@@ -430,6 +436,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         const int m = cpp > 1 ? cpp : (left < geo.chains_per_launch ? left : geo.chains_per_launch);
         a.n_chains = m;
         a.chains_per_pass = cpp;
+        if (cpp == 1) a.waves = waves_single;
         if (cpp > cpp_used) cpp_used = cpp;
         a.xi = (const double*)c->xi.p + (size_t)c0 * T * K;
         a.gam = (const double*)c->gam.p + (size_t)c0 * T;
