@@ -417,7 +417,10 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     // chains per pass: when the panels are NOT register-resident one read of X can serve up to
     // 8 chains (one leader wave per chain); 0 = automatic, 1 = off
     int cpp_max = 1;
-    if (geo.mode != 0 && n_chains > 1 && c->tune.chains_per_pass != 1) {
+    // (register residency: only the whole-chip form, one chain bundle per launch, one panel per
+    // wave; the one-XCD-per-chain form already runs 8 chains side by side)
+    const bool reg_multi_ok = geo.mode == 0 && geo.nslot < 8 && geo.G > 1 && geo.ppw == 1;
+    if ((geo.mode != 0 || reg_multi_ok) && n_chains > 1 && c->tune.chains_per_pass != 1) {
         // every chain of a pass needs a leader wave: widen the workgroup if the panels alone
         // would ask for fewer waves (the extra waves own no panel, they only lead a chain)
         int want = n_chains >= 8 ? 8 : n_chains >= 4 ? 4 : 2;
@@ -426,6 +429,10 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         if (a.waves < want && c->tune.waves_per_group <= 0) a.waves = want;
         cpp_max = a.waves >= 8 ? 8 : a.waves >= 4 ? 4 : a.waves >= 2 ? 2 : 1;
         if (cpp_max > want) cpp_max = want;
+        if (reg_multi_ok) {
+            const int cap = bmc::gibbs_reg_multi_cap(K, a.P.f32 != 0, a.P.vec);
+            if (cpp_max > cap) cpp_max = cap < 2 ? 1 : cap;
+        }
     }
     const int waves_single = geo.waves;
     int launches = 0, cpp_used = 1;

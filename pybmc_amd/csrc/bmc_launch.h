@@ -138,6 +138,7 @@ hipError_t launch_uniform_fill(uint64_t seed, int64_t n, double* out, hipStream_
 
 size_t gibbs_lds_bytes(const GibbsArgs& a);
 int gibbs_reg_capacity(int k, int f32, int rows_per_lane);  // 1 if that many rows of k columns fit in VGPRs
+int gibbs_reg_multi_cap(int k, bool f32, int vec);  // most chains per pass in register residency
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s);
 
 }  // namespace bmc

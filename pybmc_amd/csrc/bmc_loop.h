@@ -246,6 +246,74 @@ struct PanelStore {
         }
     }
 
+    // register residency, CPP chains per pass: u is [CPP][kpad] in LDS; per chain the operation
+    // order is that of partial_rss below (four FMA chains per row, then (a0+a1)+(a2+a3)).
+    // Left to itself hipcc issues all CPP*KMAX LDS reads of u before the first FMA and spills;
+    // here the address of block b's reads is made to depend (through an empty asm) on an
+    // accumulator of block b-2, so at most two blocks of UB values of u are live at a time.
+    template <int CPP>
+    __device__ __forceinline__ void partial_rss_reg_multi(const double* u, int kpad,
+                                                          double (&s)[CPP]) const {
+        static_assert(MODE == MODE_REG, "register residency only");
+        typedef const __attribute__((address_space(3))) double lds_cd;
+        constexpr int UB = (KMAX < 8 || KMAX * VEC * (int)sizeof(T) >= 256) ? 4 : 8;
+        lds_cd* ub = (lds_cd*)u;
+        double tok1[VEC][4], tok2[VEC][4];   // the accumulators one and two blocks back
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tok1[v][q] = tok2[v][q] = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) {
+            double acc[PPW][VEC][4];
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    acc[i][v][0] = (double)yr[i][v];
+                    acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
+                }
+#pragma unroll
+            for (int jb = 0; jb < KMAX; jb += UB) {
+                int off = c * kpad + jb;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    asm volatile("" : "+v"(off) : "v"(tok2[v][0]), "v"(tok2[v][1]), "v"(tok2[v][2]),
+                                 "v"(tok2[v][3]));
+                lds_cd* uc = ub + off;
+#pragma unroll
+                for (int j = 0; j < UB; j += 4) {
+                    const double u0 = uc[j], u1 = uc[j + 1], u2 = uc[j + 2], u3 = uc[j + 3];
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            acc[i][v][0] = fma(-as_f64_in_loop(xr[i][jb + j][v]), u0, acc[i][v][0]);
+                            acc[i][v][1] = fma(-as_f64_in_loop(xr[i][jb + j + 1][v]), u1, acc[i][v][1]);
+                            acc[i][v][2] = fma(-as_f64_in_loop(xr[i][jb + j + 2][v]), u2, acc[i][v][2]);
+                            acc[i][v][3] = fma(-as_f64_in_loop(xr[i][jb + j + 3][v]), u3, acc[i][v][3]);
+                        }
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        tok2[v][q] = tok1[v][q];
+                        tok1[v][q] = acc[PPW - 1][v][q];
+                    }
+            }
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double r = (acc[i][v][0] + acc[i][v][1]) + (acc[i][v][2] + acc[i][v][3]);
+                    t = fma(r, r, t);
+                }
+            s[c] = t;
+        }
+    }
+
     // this lane's share of sum (y - X u)^2 over the wave's panels; u_lds zero-padded to 64
     __device__ __forceinline__ double partial_rss(const double* __restrict__ u_lds) const {
         double s = 0.0;
@@ -337,7 +405,10 @@ __device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const 
                                                 const double* __restrict__ u, int kpad, int K,
                                                 double (&s)[CPP]) {
     constexpr int RP = 64 * VEC;
-    constexpr int UN = 16;
+    // reads in flight per wave, bounded so that the CPP*VEC*2 accumulators and the staged
+    // columns fit the 256-VGPR budget without spilling (fewer reads matter less here: with
+    // many chains per pass the loop is FMA-bound, not latency-bound)
+    constexpr int UN = (64 / (CPP * VEC)) >= 16 ? 16 : (64 / (CPP * VEC)) >= 4 ? (64 / (CPP * VEC)) : 4;
     double a0[CPP][VEC], a1[CPP][VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {

@@ -43,6 +43,9 @@ namespace bmc {
 template <typename T, int VEC, int MODE, int KMAX, int PPW, bool SINGLE = false>
 __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
+    // lane-chunks of 64 columns: register residency means K <= 64, so one chunk is known at
+    // compile time (fewer live registers and no dead branches in the leader's serial phase)
+    constexpr int KCH = (MODE == MODE_REG) ? 1 : MAX_KCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = a.P.k;
     const int C = a.n_chains, G = a.G;
@@ -89,11 +92,11 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
 
     // sigma2 = sp_eff / g_eff; starts at the OLS value (inference_utils.py:37)
     double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
-    double xi_next[MAX_KCH], lam_r[MAX_KCH], c1_r[MAX_KCH], c2_r[MAX_KCH];
+    double xi_next[KCH], lam_r[KCH], c1_r[KCH], c2_r[KCH];
     double gam_next = 0.0;
     if (wave == 0) {
 #pragma unroll
-        for (int ch = 0; ch < MAX_KCH; ++ch) {
+        for (int ch = 0; ch < KCH; ++ch) {
             const int j = ch * 64 + lane;
             xi_next[ch] = (j < K && T_it > 0) ? xi[j] : 0.0;
             lam_r[ch] = j < K ? a.lam[j] : 0.0;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
         STAMP(7);
         if (wave == 0) {
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 if (ch * 64 < K && j < K) {
                     const double D = fma(lam_r[ch], g_eff, sp_eff);
@@ -131,16 +134,16 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
         const double gam_t = gam_next;
         if (wave == 0 && t + 1 < T_it) {  // prefetch next iteration's variates
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
             }
             gam_next = gam[t + 1];
         }
-        double u_rec[MAX_KCH], sp_rec = 0.0, g_rec = 1.0;
+        double u_rec[KCH], sp_rec = 0.0, g_rec = 1.0;
         if (recorder) {  // copy now (wave 0 rewrites u_lds after its gather); store later
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 u_rec[ch] = (ch * 64 < K && j < K) ? u_lds[j] : 0.0;
             }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
         if (recorder) {
             // row t = [u_t, .]; sigma of the PREVIOUS row (its sp, g were final at B1)
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 if (ch * 64 < K && j < K) uout[t * (K + 1) + j] = u_rec[ch];
             }
@@ -194,10 +197,12 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
 // state, and -- in group 0 -- its recorded draws); all waves accumulate CPP partial sums per
 // panel column.  Arithmetic per chain is that of gibbs_loop_kernel, operation for operation.
 // ======================================================================================
-template <typename T, int VEC, int MODE, int CPP>
+template <typename T, int VEC, int MODE, int CPP, int KMAX = 0, int PPW = 0>
 __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
-    static_assert(MODE != MODE_REG, "several chains per pass: LDS or streaming residency");
+    // lane-chunks of 64 columns: register residency means K <= 64, so one chunk is known at
+    // compile time (fewer live registers and no dead branches in the leader's serial phase)
+    constexpr int KCH = (MODE == MODE_REG) ? 1 : MAX_KCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = a.P.k, G = a.G;
     const int g = blockIdx.x;             // one bundle of CPP chains per launch
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     for (int j = tid; j < kpad * CPP; j += blockDim.x) u_lds[j] = 0.0;
     if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; }
 
-    PanelStore<T, VEC, MODE, 0, 0> store;
+    PanelStore<T, VEC, MODE, KMAX, PPW> store;
     store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y));
 
     const size_t chain_stride = (size_t)3 * a.gran_stride;
@@ -237,11 +242,11 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     double* u_mine = u_lds + (size_t)chain * kpad;
 
     double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
-    double xi_next[MAX_KCH], lam_r[MAX_KCH], c1_r[MAX_KCH], c2_r[MAX_KCH];
+    double xi_next[KCH], lam_r[KCH], c1_r[KCH], c2_r[KCH];
     double gam_next = 0.0;
     if (leader) {
 #pragma unroll
-        for (int ch = 0; ch < MAX_KCH; ++ch) {
+        for (int ch = 0; ch < KCH; ++ch) {
             const int j = ch * 64 + lane;
             xi_next[ch] = (j < K && T_it > 0) ? xi[j] : 0.0;
             lam_r[ch] = j < K ? a.lam[j] : 0.0;
@@ -253,11 +258,11 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
 
     for (int64_t t = 0; t < T_it; ++t) {
         const unsigned epoch = (unsigned)(t + 1);
-        double u_rec[MAX_KCH];
+        double u_rec[KCH];
         const double sp_rec = sp_eff, g_rec = g_eff;   // sigma2 of the previous row
         if (leader) {
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 u_rec[ch] = 0.0;
                 if (ch * 64 < K && j < K) {
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         const double gam_t = gam_next;
         if (leader && t + 1 < T_it) {
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
             }
@@ -283,11 +288,12 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         double s[CPP];
 #pragma unroll
         for (int c = 0; c < CPP; ++c) s[c] = 0.0;
-        for (int q = store.wave; q < store.npl; q += store.nw) {
+        if constexpr (MODE == MODE_REG) store.template partial_rss_reg_multi<CPP>(u_lds, kpad, s);
+        for (int q = store.wave; MODE != MODE_REG && q < store.npl; q += store.nw) {
             if constexpr (MODE == MODE_LDS) {
                 panel_rss_multi<T, VEC, CPP>(store.Xs + (size_t)q * K * RP + lane * VEC,
                                              store.ys + q * RP + lane * VEC, u_lds, kpad, K, s);
-            } else {
+            } else if constexpr (MODE == MODE_STREAM) {
                 const int64_t p = g + (int64_t)q * G;
                 panel_rss_multi<T, VEC, CPP>(store.Xg + p * (int64_t)K * RP + lane * VEC,
                                              store.yg + p * RP + lane * VEC, u_lds, kpad, K, s);
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         if (leader) {
             if (g == 0) {   // this chain's row t, and sigma of its previous row
 #pragma unroll
-                for (int ch = 0; ch < MAX_KCH; ++ch) {
+                for (int ch = 0; ch < KCH; ++ch) {
                     const int j = ch * 64 + lane;
                     if (ch * 64 < K && j < K) uout[t * (K + 1) + j] = u_rec[ch];
                 }
@@ -623,12 +629,70 @@ static hipError_t launch_multi_t(const GibbsArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// register residency with several chains per pass: one panel per wave (PPW = 1).  The panel
+// (KMAX*VEC values) plus two blocks of u plus the leaders' state must fit 256 VGPRs: the most
+// chains per pass that hipcc compiles without scratch, per (columns, storage type, rows per lane)
+static constexpr int reg_multi_cap(int kmax, bool f32, int vec) {
+    if (vec == 1) return 8;
+    if (vec == 2) return kmax * (f32 ? 4 : 8) >= 256 ? 4 : 8;   // 128 VGPRs of panel: 4 chains
+    return 0;
+}
+int gibbs_reg_multi_cap(int k, bool f32, int vec) {
+    const int kmax = k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : 0;
+    return kmax ? reg_multi_cap(kmax, f32, vec) : 0;
+}
+
+// register residency with several chains per pass: one panel per wave (PPW = 1)
+template <typename T, int VEC, int KMAX>
+static hipError_t launch_multi_reg_k(const GibbsArgs& a, hipStream_t s) {
+    const size_t lds = gibbs_lds_bytes(a);
+#define BMC_MR(C)                                                                                \
+    do {                                                                                         \
+        hipError_t e = hipFuncSetAttribute(                                                      \
+            (const void*)gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1>,                       \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        if (e != hipSuccess) return e;                                                           \
+        hipLaunchKernelGGL((gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1>), dim3(a.G),        \
+                           dim3(64 * a.waves), lds, s, a);                                       \
+        return hipGetLastError();                                                                \
+    } while (0)
+    // only the combinations that fit the 256-VGPR budget without spilling are built
+    constexpr int CMAX = reg_multi_cap(KMAX, sizeof(T) == 4, VEC);
+    switch (a.chains_per_pass) {
+        case 2: if constexpr (CMAX >= 2) BMC_MR(2); break;
+        case 4: if constexpr (CMAX >= 4) BMC_MR(4); break;
+        case 8: if constexpr (CMAX >= 8) BMC_MR(8); break;
+    }
+#undef BMC_MR
+    return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t launch_multi_reg(const GibbsArgs& a, hipStream_t s) {
+    if (a.reg_ppw != 1) return hipErrorInvalidValue;
+    const int k = a.P.k;
+    if (a.P.vec == 1) {
+        if (k <= 8) return launch_multi_reg_k<T, 1, 8>(a, s);
+        if (k <= 16) return launch_multi_reg_k<T, 1, 16>(a, s);
+        if (k <= 32) return launch_multi_reg_k<T, 1, 32>(a, s);
+        if (k <= 64) return launch_multi_reg_k<T, 1, 64>(a, s);
+    } else if (a.P.vec == 2) {
+        if (k <= 8) return launch_multi_reg_k<T, 2, 8>(a, s);
+        if (k <= 16) return launch_multi_reg_k<T, 2, 16>(a, s);
+        if (k <= 32) return launch_multi_reg_k<T, 2, 32>(a, s);
+        if constexpr (sizeof(T) == 4)
+            if (k <= 64) return launch_multi_reg_k<T, 2, 64>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
     if (a.chains_per_pass > 1) {
         // one bundle of chains_per_pass chains; needs a leader wave per chain
-        if (!geometry_ok(a) || a.mode == MODE_REG || a.waves < a.chains_per_pass ||
-            a.n_chains != a.chains_per_pass)
+        if (!geometry_ok(a) || a.waves < a.chains_per_pass || a.n_chains != a.chains_per_pass)
             return hipErrorInvalidValue;
+        if (a.mode == MODE_REG)
+            return a.P.f32 ? launch_multi_reg<float>(a, s) : launch_multi_reg<double>(a, s);
         return a.P.f32 ? launch_multi_t<float>(a, s) : launch_multi_t<double>(a, s);
     }
     if (!geometry_ok(a) || a.n_chains < 1 || a.n_chains > a.nslot) return hipErrorInvalidValue;

@@ -456,6 +456,44 @@ def test_several_chains_per_pass(n, k, res, nch):
         assert np.abs(out[c] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n,k,dt,nch", [(100000, 32, np.float64, 8), (120000, 7, np.float64, 5),
+                                        (200000, 64, np.float32, 8), (150000, 20, np.float32, 4)])
+def test_several_chains_per_pass_register_residency(n, k, dt, nch):
+    """Whole-chip register residency (one panel per wave, the chain spread over all XCDs): the
+    resident panels serve up to 8 chains per pass.  Each chain must reproduce, to rounding of the
+    exchange-free arithmetic, what it draws when it has the chip to itself, and the replayed
+    oracle chain (float64 storage) in every slot."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(n + k)
+    X = (rng.standard_normal((n, k)) / np.sqrt(n)).astype(dt)
+    y = (X.astype(np.float64) @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)).astype(dt)
+    prior = (np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+    ctx.set_problem(y, np.asfortranarray(X), dtype=dt)
+    ctx.set_prior(*prior)
+    T = 300
+    seeds = np.arange(nch) + 11
+    ctx.set_tuning(residency=1, chains_per_pass=1)
+    solo, st1 = ctx.gibbs_run(nch, T, seeds=seeds)
+    assert st1["chains_per_pass"] == 1 and st1["residency"] == 1
+    ctx.set_tuning(residency=1, chains_per_pass=0)
+    shared, st = ctx.gibbs_run(nch, T, seeds=seeds)
+    ctx.set_tuning()
+    assert st["residency"] == 1 and st["chains_per_pass"] in (2, 4, 8)
+    assert st["launches"] < st1["launches"]
+    assert np.abs(shared - solo).max() < 1e-11 * max(1.0, np.abs(solo).max())
+    if dt == np.float64:
+        Xd, yd = X.astype(np.float64), y.astype(np.float64)
+        st_o = O.chain_setup(yd, Xd, prior)
+        Z, G = O.reference_streams(5, 6, 60, k, O.gamma_shape(st_o))
+        ref, trace = O.gibbs_replay(yd, Xd, 60, prior, Z, G, return_sigma2=True)
+        W, lam, _ = ctx.basis()
+        xi = O.innovations_in_basis(st_o, yd, Xd, ref, W, lam, trace)
+        out, st = ctx.gibbs_run(4, 60, xi=np.repeat(xi[None], 4, 0), g=np.repeat(G[None], 4, 0))
+        assert st["chains_per_pass"] in (2, 4) and st["residency"] == 1
+        for c in range(4):
+            assert np.abs(out[c] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n,k,dt,res", [(200000, 64, np.float32, 1), (50000, 256, np.float64, 3)])
 def test_full_size_c4_c5_properties(n, k, dt, res):
     """BASELINE configs C4 (N = 200000, K = 64, float32 storage, panels in registers across the
