@@ -6,6 +6,12 @@
 namespace bmc {
 
 // Storage description of the panelised problem (see bmc_dev.h "panel layout").
+// u64 words between the granule pairs of consecutive groups in a (chain, parity) slot
+#ifndef BMC_GRAN_PAIR_STRIDE
+#define BMC_GRAN_PAIR_STRIDE 8
+#endif
+constexpr int GRAN_PAIR_STRIDE = BMC_GRAN_PAIR_STRIDE;
+
 struct Panels {
     const void* X;   // [NP][K][RP] of T
     const void* y;   // [NP*RP] of T

@@ -61,6 +61,12 @@ __host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bo
 // XCD's L2 (workgroup scope: global_store sc0) and the L1-bypassing agent-scope load
 // (global_load sc1) is served by the same L2.  Otherwise the store is agent scope
 // (sc1, write-through) and visible to every XCD.
+// Granule i of a (chain, parity) slot: the pair (high word, low word) of group i/2 sits
+// GRAN_PAIR_STRIDE words after the pair of group i/2 - 1.
+__device__ __forceinline__ size_t gran_at(int i) {
+    return (size_t)(i >> 1) * GRAN_PAIR_STRIDE + (i & 1);
+}
+
 template <bool LOCAL>
 __device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned value) {
     const gu64 w = ((gu64)epoch << 32) | (gu64)value;
@@ -74,6 +80,36 @@ __device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned va
 __device__ __forceinline__ bool granule_gather(const gu64* gp, int n2, unsigned epoch, int lane,
                                                gu64 (&x)[MAX_GRAN_REG]) {
     unsigned long long t_start = 0;
+#ifndef BMC_POLL_DEPTH
+#define BMC_POLL_DEPTH 2
+#endif
+    if (BMC_POLL_DEPTH > 1 && n2 <= 64) {
+        // the usual case, one granule per lane: keep BMC_POLL_DEPTH reads in flight, so the
+        // epoch is seen one load round trip / depth after it lands instead of up to a full one
+#pragma unroll
+        for (int r = 1; r < MAX_GRAN_REG; ++r) x[r] = 0;
+        const bool have = lane < n2;
+        const gu64* p = gp + gran_at(have ? lane : 0);
+        gu64 q[BMC_POLL_DEPTH];
+#pragma unroll
+        for (int d = 0; d < BMC_POLL_DEPTH - 1; ++d) q[d] = granule_load(p);
+        for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+            for (int d = 0; d < BMC_POLL_DEPTH; ++d) {
+                q[(d + BMC_POLL_DEPTH - 1) % BMC_POLL_DEPTH] = granule_load(p);
+                const gu64 w = q[d];
+                if (__all(!have || (unsigned)(w >> 32) == epoch)) {
+                    x[0] = have ? w : 0;
+                    return true;
+                }
+            }
+            if ((spins & 0x7f) == 0x7f) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t_start == 0) t_start = now;
+                else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
+            }
+        }
+    }
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
@@ -82,7 +118,7 @@ __device__ __forceinline__ bool granule_gather(const gu64* gp, int n2, unsigned 
             if (r * 64 < n2) {
                 const int idx = r * 64 + lane;
                 if (idx < n2) {
-                    x[r] = granule_load(gp + idx);
+                    x[r] = granule_load(gp + gran_at(idx));
                     ok = ok && ((unsigned)(x[r] >> 32) == epoch);
                 }
             }
@@ -382,14 +418,10 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
     s = red[0];
     for (int w = 1; w < nw; ++w) s += red[w];
     if constexpr (SINGLE) return s;
-    if (lane == 0) {
-        if (local) {
-            granule_put<true>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));
-            granule_put<true>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(s));
-        } else {
-            granule_put<false>(gp + 2 * g, epoch, (unsigned)__double2hiint(s));
-            granule_put<false>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(s));
-        }
+    if (lane < 2) {   // lane 0 the high word, lane 1 the low word: one store instruction
+        const unsigned w = lane == 0 ? (unsigned)__double2hiint(s) : (unsigned)__double2loint(s);
+        if (local) granule_put<true>(gp + gran_at(2 * g + lane), epoch, w);
+        else granule_put<false>(gp + gran_at(2 * g + lane), epoch, w);
     }
     gu64 x[MAX_GRAN_REG];
     ok = granule_gather(gp, 2 * G, epoch, lane, x);
@@ -472,14 +504,10 @@ __device__ __forceinline__ double group_allreduce_multi(const double (&s)[CPP], 
     double t = red[wave * 8];
     for (int w = 1; w < nw; ++w) t += red[wave * 8 + w];
     gu64* gp = gp_chain0 + (size_t)wave * chain_stride;
-    if (lane == 0) {
-        if (local) {
-            granule_put<true>(gp + 2 * g, epoch, (unsigned)__double2hiint(t));
-            granule_put<true>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(t));
-        } else {
-            granule_put<false>(gp + 2 * g, epoch, (unsigned)__double2hiint(t));
-            granule_put<false>(gp + 2 * g + 1, epoch, (unsigned)__double2loint(t));
-        }
+    if (lane < 2) {   // lane 0 the high word, lane 1 the low word: one store instruction
+        const unsigned w = lane == 0 ? (unsigned)__double2hiint(t) : (unsigned)__double2loint(t);
+        if (local) granule_put<true>(gp + gran_at(2 * g + lane), epoch, w);
+        else granule_put<false>(gp + gran_at(2 * g + lane), epoch, w);
     }
     gu64 x[MAX_GRAN_REG];
     ok = granule_gather(gp, 2 * G, epoch, lane, x);
