@@ -410,8 +410,8 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     a.panels_per_group = geo.ppg;
     a.dbg = nullptr;
 #ifdef BMC_STAMPS
-    if ((rc = ensure(c, c->dbg, 8 * sizeof(long long)))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 8 * sizeof(long long), c->stream));
+    if ((rc = ensure(c, c->dbg, 12 * sizeof(long long)))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 12 * sizeof(long long), c->stream));
     a.dbg = (long long*)c->dbg.p;
 #endif
     // chains per pass: when the panels are NOT register-resident one read of X can serve up to
@@ -1152,7 +1152,7 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
 // Diagnostic build only; not part of the public ABI.
 int bmc_dev_get_stamps(bmc_ctx* c, long long* out8) {
     if (!c || !out8 || !c->dbg.p) return BMC_EINVAL;
-    HIPCHK(c, hipMemcpy(out8, c->dbg.p, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out8, c->dbg.p, 12 * sizeof(long long), hipMemcpyDeviceToHost));
     return BMC_OK;
 }
 #endif

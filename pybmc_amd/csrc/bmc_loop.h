@@ -50,7 +50,13 @@ __host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bo
             last_ = now_;                                                             \
         }                                                                             \
     } while (0)
+#define GSTAMP(i) STAMP(i)
+#define STAMP_PARAMS , bool stamping, unsigned long long (&acc_)[12], unsigned long long& last_
+#define STAMP_ARGS , stamping, acc_, last_
 #else
+#define GSTAMP(i)
+#define STAMP_PARAMS
+#define STAMP_ARGS
 // Product build: no stamp; the phase boundary stays a scheduling fence (same-box A/B: neutral
 // at C2, 2.6 % faster for single-workgroup chains than hipcc's own interleaving of the phases).
 #define STAMP(i) __builtin_amdgcn_sched_barrier(0)
@@ -76,40 +82,40 @@ __device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned va
         __hip_atomic_store(g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Gather n2 granules of `epoch`; returns false when the bounded spin expired.
+// Gather n2 <= 64 granules of `epoch`, one per lane (the usual case: G <= 32).  Two reads are
+// kept in flight, so the epoch is seen half a load round trip after it lands instead of up
+// to a full one (three or four in flight were slower: same-box A/B).  Returns false when the
+// bounded spin expired.  Lanes >= n2 get 0.
+__device__ __forceinline__ bool granule_gather1(const gu64* gp, int n2, unsigned epoch, int lane,
+                                                gu64& x STAMP_PARAMS) {
+    unsigned long long t_start = 0;
+    const bool have = lane < n2;
+    const gu64* p = gp + gran_at(have ? lane : 0);
+    gu64 q0 = granule_load(p), q1;
+    for (unsigned spins = 0;; ++spins) {
+        q1 = granule_load(p);
+#ifdef BMC_STAMPS
+        if (stamping) acc_[9] += 1;
+#endif
+        if (__all(!have || (unsigned)(q0 >> 32) == epoch)) { x = have ? q0 : 0; return true; }
+        q0 = granule_load(p);
+#ifdef BMC_STAMPS
+        if (stamping) acc_[9] += 1;
+#endif
+        if (__all(!have || (unsigned)(q1 >> 32) == epoch)) { x = have ? q1 : 0; return true; }
+        if ((spins & 0x7f) == 0x7f) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_start == 0) t_start = now;
+            else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
+        }
+    }
+}
+
+// Gather n2 granules of `epoch` (any n2 <= 64 * MAX_GRAN_REG); returns false when the bounded
+// spin expired.
 __device__ __forceinline__ bool granule_gather(const gu64* gp, int n2, unsigned epoch, int lane,
                                                gu64 (&x)[MAX_GRAN_REG]) {
     unsigned long long t_start = 0;
-#ifndef BMC_POLL_DEPTH
-#define BMC_POLL_DEPTH 2
-#endif
-    if (BMC_POLL_DEPTH > 1 && n2 <= 64) {
-        // the usual case, one granule per lane: keep BMC_POLL_DEPTH reads in flight, so the
-        // epoch is seen one load round trip / depth after it lands instead of up to a full one
-#pragma unroll
-        for (int r = 1; r < MAX_GRAN_REG; ++r) x[r] = 0;
-        const bool have = lane < n2;
-        const gu64* p = gp + gran_at(have ? lane : 0);
-        gu64 q[BMC_POLL_DEPTH];
-#pragma unroll
-        for (int d = 0; d < BMC_POLL_DEPTH - 1; ++d) q[d] = granule_load(p);
-        for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-            for (int d = 0; d < BMC_POLL_DEPTH; ++d) {
-                q[(d + BMC_POLL_DEPTH - 1) % BMC_POLL_DEPTH] = granule_load(p);
-                const gu64 w = q[d];
-                if (__all(!have || (unsigned)(w >> 32) == epoch)) {
-                    x[0] = have ? w : 0;
-                    return true;
-                }
-            }
-            if ((spins & 0x7f) == 0x7f) {
-                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                if (t_start == 0) t_start = now;
-                else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
-            }
-        }
-    }
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
@@ -130,6 +136,21 @@ __device__ __forceinline__ bool granule_gather(const gu64* gp, int n2, unsigned 
             else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
         }
     }
+}
+
+// one granule per lane: even lane 2g' holds the high word of group g', odd lane the low
+// word; lanes past the last group hold 0.  Both lanes of a pair assemble group g's double, so
+// the sum over g' is wave_sum without its first step (which adds the two lanes of a pair).
+__device__ __forceinline__ double granule_sum1(gu64 x, int lane) {
+    const int w = (int)(unsigned)x;
+    const int other = __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true);
+    double v = (lane & 1) == 0 ? __hiloint2double(w, other) : __hiloint2double(other, w);
+    v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);         // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);         // row_mirror
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
+    const double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return ((r0 + r1) + r2) + r3;
 }
 
 // even lane 2g' holds the high word of group g', odd lane the low word -> sum over g'
@@ -406,26 +427,60 @@ struct PanelStore {
 // SINGLE = the chain lives in ONE workgroup (G == 1): nothing to exchange, the group total is
 // the chain total.  A template parameter, not a run-time test, so that the multi-group code is
 // byte-for-byte what it was (a run-time `if (G == 1)` cost the C2 path 4 %).
-template <bool SINGLE = false>
-__device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
-                                                  int wave, int nw, int lane, unsigned epoch,
-                                                  bool local, bool& ok) {
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    ok = true;
-    if (wave != 0) return 0.0;
-    s = red[0];
-    for (int w = 1; w < nw; ++w) s += red[w];
-    if constexpr (SINGLE) return s;
+// `red` holds 8 per-wave slots; the slots of waves that do not exist stay 0 (zeroed by the
+// caller before the loop).  Lane w < 8 reads slot w and three DPP steps add them in a fixed
+// tree, ((r0+r1)+(r2+r3)) + ((r7+r6)+(r5+r4)): no trip count, one LDS read, 4 VGPRs.
+__device__ __forceinline__ double sum_wave_slots(const double* red, int lane) {
+    double v = lane < 8 ? red[lane] : 0.0;
+    v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);         // row_half_mirror
+    return readlane_f64(v, 0);
+}
+
+template <bool LOCAL>
+__device__ __forceinline__ void publish_pair(gu64* gp, int g, int lane, unsigned epoch, double s) {
     if (lane < 2) {   // lane 0 the high word, lane 1 the low word: one store instruction
         const unsigned w = lane == 0 ? (unsigned)__double2hiint(s) : (unsigned)__double2loint(s);
-        if (local) granule_put<true>(gp + gran_at(2 * g + lane), epoch, w);
-        else granule_put<false>(gp + gran_at(2 * g + lane), epoch, w);
+        granule_put<LOCAL>(gp + gran_at(2 * g + lane), epoch, w);
+    }
+}
+
+// publish this group's total, gather the chain's G totals, sum them in group order
+__device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g, int lane,
+                                               unsigned epoch, bool local, bool& ok STAMP_PARAMS) {
+    // gp is opaque from here on: the per-lane granule addresses are then computed where they
+    // are used instead of being kept in VGPRs across the whole iteration loop
+    asm volatile("" : "+s"(gp));
+    if (local) publish_pair<true>(gp, g, lane, epoch, s);
+    else publish_pair<false>(gp, g, lane, epoch, s);
+    if (G <= 32) {
+        gu64 x;
+        ok = granule_gather1(gp, 2 * G, epoch, lane, x STAMP_ARGS);
+        GSTAMP(5);
+        const double tot = ok ? granule_sum1(x, lane) : 0.0;
+        GSTAMP(8);
+        return tot;
     }
     gu64 x[MAX_GRAN_REG];
     ok = granule_gather(gp, 2 * G, epoch, lane, x);
     return ok ? granule_sum(x, 2 * G, lane) : 0.0;
+}
+
+template <bool SINGLE = false>
+__device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
+                                                  int wave, int nw, int lane, unsigned epoch,
+                                                  bool local, bool& ok STAMP_PARAMS) {
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    GSTAMP(3);
+    __syncthreads();
+    ok = true;
+    if (wave != 0) return 0.0;
+    s = sum_wave_slots(red, lane);
+    GSTAMP(4);
+    if constexpr (SINGLE) return s;
+    return exchange_sum(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS);
 }
 
 // ---- several chains per pass (streaming / LDS residency) ---------------------------------
@@ -501,17 +556,13 @@ __device__ __forceinline__ double group_allreduce_multi(const double (&s)[CPP], 
     __syncthreads();
     ok = true;
     if (wave >= CPP) return 0.0;
-    double t = red[wave * 8];
-    for (int w = 1; w < nw; ++w) t += red[wave * 8 + w];
-    gu64* gp = gp_chain0 + (size_t)wave * chain_stride;
-    if (lane < 2) {   // lane 0 the high word, lane 1 the low word: one store instruction
-        const unsigned w = lane == 0 ? (unsigned)__double2hiint(t) : (unsigned)__double2loint(t);
-        if (local) granule_put<true>(gp + gran_at(2 * g + lane), epoch, w);
-        else granule_put<false>(gp + gran_at(2 * g + lane), epoch, w);
-    }
-    gu64 x[MAX_GRAN_REG];
-    ok = granule_gather(gp, 2 * G, epoch, lane, x);
-    return ok ? granule_sum(x, 2 * G, lane) : 0.0;
+    const double t = sum_wave_slots(red + wave * 8, lane);
+#ifdef BMC_STAMPS
+    bool stamping = false;
+    unsigned long long acc_[12] = {}, last_ = 0;
+#endif
+    return exchange_sum(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane, epoch, local,
+                        ok STAMP_ARGS);
 }
 
 }  // namespace bmc

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
 
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad; j += blockDim.x) u_lds[j] = 0.0;
+    if (tid < 64) red[tid] = 0.0;   // slots of absent waves stay 0 (sum_wave_slots)
     if (tid == 0) { ctl[0] = a.sigma2_init; ctl[1] = 0.0; ctl[2] = 0.0; ctl[3] = 1.0; }
 
     PanelStore<T, VEC, MODE, KMAX, PPW> store;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
 
 #ifdef BMC_STAMPS
     const bool stamping = a.dbg != nullptr && blockIdx.x == 0 && wave == 0;
-    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+    unsigned long long acc_[12] = {}, last_ = 0;
     if (stamping) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
     for (int64_t t = 0; t < T_it; ++t) {
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
         STAMP(2);
         bool got;
         const double rss = group_allreduce<SINGLE>(part, red, gr + (size_t)(t & 1) * a.gran_stride,
-                                                   G, g, wave, nw, lane, epoch, local, got);
-        STAMP(5);
+                                                   G, g, wave, nw, lane, epoch, local, got STAMP_ARGS);
+        STAMP(8);
         if (recorder) {
             // row t = [u_t, .]; sigma of the PREVIOUS row (its sp, g were final at B1)
 #pragma unroll
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
     }
 #ifdef BMC_STAMPS
     if (stamping && lane == 0)
-        for (int i = 0; i < 8; ++i) a.dbg[i] = (long long)acc_[i];
+        for (int i = 0; i < 12; ++i) a.dbg[i] = (long long)acc_[i];
 #endif
     __syncthreads();
     if (recorder && lane == 0 && T_it > 0 && ctl[1] == 0.0)
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     double* ctl = reinterpret_cast<double*>(smem + L.ctl);   // [1] abort, [2] local
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad * CPP; j += blockDim.x) u_lds[j] = 0.0;
+    if (tid < 64) red[tid] = 0.0;   // slots of absent waves stay 0 (sum_wave_slots)
     if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; }
 
     PanelStore<T, VEC, MODE, KMAX, PPW> store;
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
 
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad; j += blockDim.x) u_lds[j] = 0.0;
+    if (tid < 64) red[tid] = 0.0;   // slots of absent waves stay 0 (sum_wave_slots)
     if (a.vt_in_lds)
         for (int e = tid; e < K * Km; e += blockDim.x) vt_lds[e] = a.Vt[e];
     if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; ctl[4] = 0.0; }
@@ -444,8 +447,12 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
         if (inside) {
             const double part = store.partial_rss(u_lds);
             bool got;
+#ifdef BMC_STAMPS
+            bool stamping = false;
+            unsigned long long acc_[12] = {}, last_ = 0;
+#endif
             const double rss_prop = group_allreduce(part, red, gr + (size_t)(nex & 1) * a.gran_stride,
-                                                    G, g, wave, nw, lane, nex + 1, local, got);
+                                                    G, g, wave, nw, lane, nex + 1, local, got STAMP_ARGS);
             ++nex;
             if (wave == 0) {
                 if (!got || iu >= a.n_unif) {

@@ -16,7 +16,7 @@ for name, n, k, dt in (("C5 50000x256 f64", 50000, 256, np.float64), ("C4 200000
     T = 2000
     ctx.gibbs_run(1, 200, seeds=[1])
     out, st = ctx.gibbs_run(1, T, seeds=[1])
-    buf = (C.c_longlong * 8)()
+    buf = (C.c_longlong * 12)()
     lib.bmc_dev_get_stamps(ctx._h, buf)
     cyc = np.array(list(buf), float) / T
     print(f"{name}: G={st['groups_per_chain']} W={st['waves_per_group']} res={st['residency']} us/iter={st['loop_ms']*1e3/T:.2f} ticks/iter={cyc.sum():.0f}")

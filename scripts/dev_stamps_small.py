@@ -20,7 +20,7 @@ for n, km, k, tune in ((629, 4, 3, dict(groups_per_chain=1, waves_per_group=4)),
         out, st = ctx.gibbs_run(1, T, seeds=[1])
     except Exception as e:
         print(n, k, tune, e); continue
-    buf = (C.c_longlong * 8)()
+    buf = (C.c_longlong * 12)()
     lib.bmc_dev_get_stamps(ctx._h, buf)
     cyc = np.array(list(buf), float) / T
     print(f"N={n} K={k} G={st['groups_per_chain']} W={st['waves_per_group']} res={st['residency']} us/iter={st['loop_ms']*1e3/T:.3f} ticks/iter={cyc.sum():.0f}")
