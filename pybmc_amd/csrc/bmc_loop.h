@@ -449,9 +449,12 @@ __device__ __forceinline__ void publish_pair(gu64* gp, int g, int lane, unsigned
 // publish this group's total, gather the chain's G totals, sum them in group order
 __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g, int lane,
                                                unsigned epoch, bool local, bool& ok STAMP_PARAMS) {
-    // gp is opaque from here on: the per-lane granule addresses are then computed where they
-    // are used instead of being kept in VGPRs across the whole iteration loop
-    asm volatile("" : "+s"(gp));
+    // gp is opaque from here on (an offset of unknown value, so that it stays a global
+    // pointer): the per-lane granule addresses are then computed where they are used instead
+    // of being kept in VGPRs across the whole iteration loop
+    size_t opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    gp += opaque0;
     if (local) publish_pair<true>(gp, g, lane, epoch, s);
     else publish_pair<false>(gp, g, lane, epoch, s);
     if (G <= 32) {

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
         }
         STAMP(0);
         __syncthreads();  // B1: u (and the previous sp, g / abort word) visible to all waves
-        if (ctl[1] != 0.0) break;
+        // the abort word is read here with u but tested after the residual pass: a test here
+        // would put an LDS round trip between the barrier and the first FMA of every wave
+        const double abort_w = ctl[1];
         STAMP(1);
 
         const double gam_t = gam_next;
@@ -154,6 +156,11 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
 
         // ---- partial rss over this group's panels, then over the chain's groups ---------
         const double part = store.partial_rss(u_lds);
+        {   // (the empty asm ties the test to `part`, or hipcc moves it back up)
+            double abort_late = abort_w;
+            asm volatile("" : "+v"(abort_late) : "v"(part));
+            if (__builtin_amdgcn_readfirstlane(__double2hiint(abort_late)) != 0) break;
+        }
         STAMP(2);
         bool got;
         const double rss = group_allreduce<SINGLE>(part, red, gr + (size_t)(t & 1) * a.gran_stride,
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
             }
         }
         __syncthreads();  // B1
-        if (ctl[1] != 0.0) break;
+        const double abort_w = ctl[1];   // tested after the residual pass (see gibbs_loop_kernel)
         const double gam_t = gam_next;
         if (leader && t + 1 < T_it) {
 #pragma unroll
@@ -300,6 +307,11 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                 panel_rss_multi<T, VEC, CPP>(store.Xg + p * (int64_t)K * RP + lane * VEC,
                                              store.yg + p * RP + lane * VEC, u_lds, kpad, K, s);
             }
+        }
+        {
+            double abort_late = abort_w;
+            asm volatile("" : "+v"(abort_late) : "v"(s[CPP - 1]));
+            if (__builtin_amdgcn_readfirstlane(__double2hiint(abort_late)) != 0) break;
         }
         bool got;
         const double rss = group_allreduce_multi<CPP>(s, red, a.gran + (size_t)(t & 1) * a.gran_stride,
