@@ -365,7 +365,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         d_samples = (double*)c->samples.p;
     }
     const Geometry geo = choose_geometry(c, n_chains);
-    const int gran_stride = ((2 * geo.G + 31) / 32) * 16 * bmc::GRAN_PAIR_STRIDE;
+    const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)(geo.chains_per_launch > 8 ? geo.chains_per_launch : 8) * 3 *
                                      gran_stride * 8)))
         return rc;
@@ -969,7 +969,7 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     std::vector<double> step(K);
     for (int j = 0; j < K; ++j) step[j] = std::sqrt(S_hat[j] * S_hat[j] * stepsize * stepsize);  // :80
     const Geometry geo = choose_geometry(c, 1);
-    const int gran_stride = ((2 * geo.G + 31) / 32) * 16 * bmc::GRAN_PAIR_STRIDE;
+    const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)3 * gran_stride * 8))) return rc;
     HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)3 * gran_stride * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, 16, c->stream));

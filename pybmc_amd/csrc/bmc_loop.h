@@ -7,7 +7,7 @@
 namespace bmc {
 
 constexpr int MAX_KCH = 4;        // K <= 256 columns (64 per lane-chunk)
-constexpr int MAX_GRAN_REG = 8;   // 2*G <= 512 granules -> G <= 256
+constexpr int MAX_GROUPS = 256;   // 8 teams of <= 32 groups (exchange_sum)
 constexpr unsigned long long SPIN_TIMEOUT_TICKS = 400000000ull;  // 4 s of s_memrealtime (100 MHz)
 
 enum { MODE_REG = 0, MODE_LDS = 1, MODE_STREAM = 2 };
@@ -82,55 +82,33 @@ __device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned va
         __hip_atomic_store(g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef BMC_POLL_DEPTH2
+#define BMC_POLL_DEPTH2 2
+#endif
 // Gather n2 <= 64 granules of `epoch`, one per lane (the usual case: G <= 32).  Two reads are
 // kept in flight, so the epoch is seen half a load round trip after it lands instead of up
 // to a full one (three or four in flight were slower: same-box A/B).  Returns false when the
 // bounded spin expired.  Lanes >= n2 get 0.
+template <int DEPTH = 2>
 __device__ __forceinline__ bool granule_gather1(const gu64* gp, int n2, unsigned epoch, int lane,
                                                 gu64& x STAMP_PARAMS) {
     unsigned long long t_start = 0;
     const bool have = lane < n2;
     const gu64* p = gp + gran_at(have ? lane : 0);
-    gu64 q0 = granule_load(p), q1;
-    for (unsigned spins = 0;; ++spins) {
-        q1 = granule_load(p);
-#ifdef BMC_STAMPS
-        if (stamping) acc_[9] += 1;
-#endif
-        if (__all(!have || (unsigned)(q0 >> 32) == epoch)) { x = have ? q0 : 0; return true; }
-        q0 = granule_load(p);
-#ifdef BMC_STAMPS
-        if (stamping) acc_[9] += 1;
-#endif
-        if (__all(!have || (unsigned)(q1 >> 32) == epoch)) { x = have ? q1 : 0; return true; }
-        if ((spins & 0x7f) == 0x7f) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t_start == 0) t_start = now;
-            else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
-        }
-    }
-}
-
-// Gather n2 granules of `epoch` (any n2 <= 64 * MAX_GRAN_REG); returns false when the bounded
-// spin expired.
-__device__ __forceinline__ bool granule_gather(const gu64* gp, int n2, unsigned epoch, int lane,
-                                               gu64 (&x)[MAX_GRAN_REG]) {
-    unsigned long long t_start = 0;
-    for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
+    gu64 q[DEPTH];
 #pragma unroll
-        for (int r = 0; r < MAX_GRAN_REG; ++r) {
-            x[r] = 0;
-            if (r * 64 < n2) {
-                const int idx = r * 64 + lane;
-                if (idx < n2) {
-                    x[r] = granule_load(gp + gran_at(idx));
-                    ok = ok && ((unsigned)(x[r] >> 32) == epoch);
-                }
-            }
+    for (int d = 0; d < DEPTH - 1; ++d) q[d] = granule_load(p);
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            q[(d + DEPTH - 1) % DEPTH] = granule_load(p);
+#ifdef BMC_STAMPS
+            if (stamping) acc_[9] += 1;
+#endif
+            const gu64 w = q[d];
+            if (__all(!have || (unsigned)(w >> 32) == epoch)) { x = have ? w : 0; return true; }
         }
-        if (__all(ok)) return true;
-        if ((spins & 0xff) == 0xff) {
+        if ((spins & 0x7f) == 0x7f) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (t_start == 0) t_start = now;
             else if (now - t_start > SPIN_TIMEOUT_TICKS) return false;
@@ -153,28 +131,16 @@ __device__ __forceinline__ double granule_sum1(gu64 x, int lane) {
     return ((r0 + r1) + r2) + r3;
 }
 
-// even lane 2g' holds the high word of group g', odd lane the low word -> sum over g'
-__device__ __forceinline__ double granule_sum(const gu64 (&x)[MAX_GRAN_REG], int n2, int lane) {
-    double part = 0.0;
-#pragma unroll
-    for (int r = 0; r < MAX_GRAN_REG; ++r) {
-        if (r * 64 < n2) {
-            const int w = (int)(unsigned)x[r];
-            const int other = __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true);
-            const double d = __hiloint2double(w, other);
-            part += ((lane & 1) == 0 && r * 64 + lane < n2) ? d : 0.0;
-        }
-    }
-    return wave_sum(part);
-}
-
 // Publish this group's XCC id, gather the chain's G ids (agent scope, always valid) and
-// decide: 1 = all groups on one XCD.  Run by wave 0; returns -1 when the spin expired.
+// decide.  G <= 32: 1 = all groups on one XCD.  G > 32 (two-level exchange, teams g mod 8):
+// 1 = every group shares its XCD with the first member of its team, i.e. each team is
+// XCD-local.  Run by wave 0; returns -1 when the spin expired.
 __device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, int lane) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
     if (lane == 0)
         __hip_atomic_store(xcc_words + g, (gu64)(xcc + 1), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    const bool teams = G > 32;
     bool same = true;
     unsigned long long t_start = 0;
     for (unsigned spins = 0;; ++spins) {
@@ -182,11 +148,15 @@ __device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, i
         same = true;
         for (int b = 0; b < G; b += 64) {
             const int idx = b + lane;
-            gu64 w = xcc + 1;
-            if (idx < G) w = __hip_atomic_load(xcc_words + idx, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && (w != 0);
-            same = same && (w == (gu64)(xcc + 1));
+            gu64 w = xcc + 1, lead = xcc + 1;
+            if (idx < G) {
+                w = __hip_atomic_load(xcc_words + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (teams)
+                    lead = __hip_atomic_load(xcc_words + (idx & 7), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = ok && (w != 0) && (lead != 0);
+            same = same && (w == lead);
         }
         if (__all(ok)) break;
         if ((spins & 0xff) == 0xff) {
@@ -446,7 +416,15 @@ __device__ __forceinline__ void publish_pair(gu64* gp, int g, int lane, unsigned
     }
 }
 
-// publish this group's total, gather the chain's G totals, sum them in group order
+// Publish this group's total, gather the chain's G totals and sum them in a fixed order.
+// G <= 32: one level (granule pairs 0..G-1).  G > 32 (the chain spans XCDs): two levels.
+// Team j = the groups g with g mod 8 = j (the hardware deals workgroups to the 8 XCDs round
+// robin, so a team normally shares an XCD and `local` then means "every team is XCD-local"):
+// the team's <= 32 totals are exchanged in pairs 32j .. 32j+31 and summed; the team's first
+// member publishes the team total in pair 256+j at agent scope; every group gathers those 8
+// pairs.  Per step every group reads one granule per lane instead of 2G/64 registers of them,
+// and only 8 stores per step cross XCDs.  The order of summation depends on G only, never
+// on where the groups really run.
 __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g, int lane,
                                                unsigned epoch, bool local, bool& ok STAMP_PARAMS) {
     // gp is opaque from here on (an offset of unknown value, so that it stays a global
@@ -455,19 +433,24 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     size_t opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
     gp += opaque0;
-    if (local) publish_pair<true>(gp, g, lane, epoch, s);
-    else publish_pair<false>(gp, g, lane, epoch, s);
-    if (G <= 32) {
-        gu64 x;
-        ok = granule_gather1(gp, 2 * G, epoch, lane, x STAMP_ARGS);
-        GSTAMP(5);
-        const double tot = ok ? granule_sum1(x, lane) : 0.0;
-        GSTAMP(8);
-        return tot;
+    const bool teams = G > 32;
+    const int team = teams ? (g & 7) : 0, rank = teams ? (g >> 3) : g;
+    const int members = teams ? ((G - team + 7) >> 3) : G;
+    gu64* gp1 = gp + gran_at(64 * team);
+    if (local) publish_pair<true>(gp1, rank, lane, epoch, s);
+    else publish_pair<false>(gp1, rank, lane, epoch, s);
+    gu64 x;
+    ok = granule_gather1(gp1, 2 * members, epoch, lane, x STAMP_ARGS);
+    GSTAMP(5);
+    double tot = ok ? granule_sum1(x, lane) : 0.0;
+    if (teams && ok) {
+        gu64* gp2 = gp + gran_at(2 * 256);
+        if (rank == 0) publish_pair<false>(gp2, team, lane, epoch, tot);
+        ok = granule_gather1<BMC_POLL_DEPTH2>(gp2, 16, epoch, lane, x STAMP_ARGS);
+        tot = ok ? granule_sum1(x, lane) : 0.0;
     }
-    gu64 x[MAX_GRAN_REG];
-    ok = granule_gather(gp, 2 * G, epoch, lane, x);
-    return ok ? granule_sum(x, 2 * G, lane) : 0.0;
+    GSTAMP(8);
+    return tot;
 }
 
 template <bool SINGLE = false>

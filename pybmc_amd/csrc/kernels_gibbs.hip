@@ -606,7 +606,7 @@ int gibbs_reg_capacity(int k, int f32, int rows_per_lane) {
 
 template <typename Args>
 static bool geometry_ok(const Args& a) {
-    return a.P.k <= 64 * MAX_KCH && a.G <= 32 * MAX_GRAN_REG && a.G >= 1 && a.waves >= 1 &&
+    return a.P.k <= 64 * MAX_KCH && a.G <= MAX_GROUPS && a.G >= 1 && a.waves >= 1 &&
            a.waves <= 8 && a.nslot >= 1 && a.nslot <= 2048;
 }
 

@@ -8,7 +8,7 @@ lib.bmc_dev_get_stamps.restype = C.c_int
 lib.bmc_dev_get_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 ctx = _lib.Context(0)
 rng = np.random.Generator(np.random.PCG64(1))
-names = ["u", "B1", "matvec", "-", "-", "wsum..gather", "s2", "top"]
+names = ["u", "B1", "matvec", "wsum", "B2+wavesum", "pub+poll(G<=32)", "s2", "top", "gsum | pub+gather+gsum(G>32)", "polls"]
 for name, n, k, dt in (("C5 50000x256 f64", 50000, 256, np.float64), ("C4 200000x64 f32", 200000, 64, np.float32)):
     X = (rng.standard_normal((n, k)) / np.sqrt(n)).astype(dt)
     y = (X.astype(float) @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)).astype(dt)
@@ -18,6 +18,6 @@ for name, n, k, dt in (("C5 50000x256 f64", 50000, 256, np.float64), ("C4 200000
     out, st = ctx.gibbs_run(1, T, seeds=[1])
     buf = (C.c_longlong * 12)()
     lib.bmc_dev_get_stamps(ctx._h, buf)
-    cyc = np.array(list(buf), float) / T
-    print(f"{name}: G={st['groups_per_chain']} W={st['waves_per_group']} res={st['residency']} us/iter={st['loop_ms']*1e3/T:.2f} ticks/iter={cyc.sum():.0f}")
+    cyc = np.array(list(buf), float)[:10] / T
+    print(f"{name}: G={st['groups_per_chain']} W={st['waves_per_group']} res={st['residency']} us/iter={st['loop_ms']*1e3/T:.2f} ticks/iter={cyc[:9].sum():.0f}")
     print("   " + "  ".join(f"{n_}:{c:.0f}" for n_, c in zip(names, cyc)))
