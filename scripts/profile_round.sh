@@ -5,7 +5,7 @@
 set -o pipefail
 TAG=${1:-r01}
 OUT=/root/repo/gpurun_out/prof_$TAG
-rm -rf $OUT
+rm -rf $OUT   # NOTE: gpurun MERGES into the local gpurun_out/: delete the local copy before the call too
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 MAIN="python3 /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra"
