@@ -1098,9 +1098,11 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
         (rc = ensure(c, c->pR, (size_t)M * a.S_pad * 8)) ||
         (rc = ensure(c, c->pBands, (size_t)(n_q > 0 ? n_q : 1) * M * 8)))
         return rc;
-    // aux block: q_index[64] i32 | cov_lo[64] | cov_hi[64] | q_gamma[64] f64 | hits[64] u64 | truth[M]
-    const size_t offQ = 0, offLo = 256, offHi = 512, offG = 768, offH = 768 + 512, offT = offH + 512;
-    if ((rc = ensure(c, c->pAux, offT + (size_t)M * 8))) return rc;
+    // aux block: q_index[64] i32 | cov_lo[64] | cov_hi[64] | q_gamma[64] f64 | hits[64] u64 |
+    //            fail_count (16 B) | truth[M] f64 | fail_points[M] i32
+    const size_t offQ = 0, offLo = 256, offHi = 512, offG = 768, offH = 768 + 512, offFC = offH + 512;
+    const size_t offT = offFC + 16, offFP = offT + (size_t)M * 8;
+    if ((rc = ensure(c, c->pAux, offFP + (size_t)M * 4))) return rc;
     char* aux = (char*)c->pAux.p;
     HIPCHK(c, hipMemsetAsync(aux, 0, offT, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->pPreds.p, preds, szP, hipMemcpyHostToDevice, c->stream));
@@ -1134,6 +1136,8 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
     a.cov_hi = (const int32_t*)(aux + offHi);
     a.bands = (double*)c->pBands.p;
     a.hits = (unsigned long long*)(aux + offH);
+    a.fail_count = (int32_t*)(aux + offFC);
+    a.fail_points = (int32_t*)(aux + offFP);
     HIPCHK(c, launch_predict(a, c->stream));
     if (n_q)
         HIPCHK(c, hipMemcpyAsync(bands_out, c->pBands.p, (size_t)n_q * M * 8, hipMemcpyDeviceToHost,

@@ -91,6 +91,8 @@ struct PredictArgs {
     int32_t n_cov;
     double* bands;         // [n_q][M]
     unsigned long long* hits;  // [n_cov], zeroed
+    int32_t* fail_points;  // [M] points the selection kernel hands to the sort kernel (or NULL)
+    int32_t* fail_count;   // [1], zeroed
 };
 hipError_t launch_predict(const PredictArgs& a, hipStream_t s);
 

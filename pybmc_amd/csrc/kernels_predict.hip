@@ -127,11 +127,16 @@ __global__ __launch_bounds__(1024) void predict_orderstat_kernel(
     const int32_t* __restrict__ q_index, const double* __restrict__ q_gamma, int32_t n_q,
     const double* __restrict__ truth, const int32_t* __restrict__ cov_lo,
     const int32_t* __restrict__ cov_hi, int32_t n_cov, double* __restrict__ bands,
-    unsigned long long* __restrict__ hits) {
+    unsigned long long* __restrict__ hits, const int32_t* __restrict__ point_list,
+    const int32_t* __restrict__ point_count) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* buf = reinterpret_cast<double*>(smem_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int64_t p = blockIdx.x; p < M; p += gridDim.x) {
+    // all points, or (second pass of the selection kernel below) the points it handed back
+    const int64_t n_points = point_list ? (int64_t)*point_count : M;
+    unsigned long long my_hits = 0;   // thread 64+c counts interval c over this workgroup's points
+    for (int64_t pi = blockIdx.x; pi < n_points; pi += gridDim.x) {
+        const int64_t p = point_list ? (int64_t)point_list[pi] : pi;
         const double* row = R + p * S_pad;
         for (int i = tid; i < NSORT; i += nt) buf[i] = i < S ? row[i] : __builtin_inf();
         __syncthreads();
@@ -159,10 +164,202 @@ __global__ __launch_bounds__(1024) void predict_orderstat_kernel(
         if (truth != nullptr && tid >= 64 && tid - 64 < n_cov) {
             const int c = tid - 64;
             const double y = truth[p];
-            if (buf[cov_lo[c]] <= y && y <= buf[cov_hi[c]]) atomicAdd(&hits[c], 1ull);
+            if (buf[cov_lo[c]] <= y && y <= buf[cov_hi[c]]) my_hits += 1;
         }
         __syncthreads();
     }
+    // one global atomic per (workgroup, interval): per-point atomics on these few addresses
+    // serialise at the memory side (4 ms for 50 000 points x 21 intervals)
+    if (my_hits) atomicAdd(&hits[tid - 64], my_hits);
+}
+
+// ----------------------------------------------------------- order statistics by selection
+// Only a few dozen ranks of each point's S draws are asked for (percentile neighbours and
+// coverage bounds), so a full sort is wasted work.  One 512-thread workgroup per point keeps the
+// draws in registers, histograms them over SEL_BINS equal-width bins of [min, max] (LDS atomics),
+// finds the bin of every requested rank from the prefix sums, collects the members of just
+// those bins (<= SEL_CAP each) and ranks them by counting inside one wave.  The values returned
+// are elements of the row, so the result is bit-identical to the sort.  A point whose requested
+// bin holds more than SEL_CAP draws (heavy ties, far outliers) is handed to the sort kernel
+// through `fail_points`.
+constexpr int SEL_BINS = 2048, SEL_CAP = 64, SEL_THREADS = 512;
+
+__device__ __forceinline__ int sel_bin(double x, double mn, double scale) {
+    const double t = (x - mn) * scale;
+    int b = (int)t;
+    return b < 0 ? 0 : (b > SEL_BINS - 1 ? SEL_BINS - 1 : b);
+}
+
+template <int VPT>
+__global__ __launch_bounds__(SEL_THREADS, 4) void predict_select_kernel(
+    const double* __restrict__ R, int32_t S, int32_t S_pad, int64_t M,
+    const int32_t* __restrict__ q_index, const double* __restrict__ q_gamma, int32_t n_q,
+    const double* __restrict__ truth, const int32_t* __restrict__ cov_lo,
+    const int32_t* __restrict__ cov_hi, int32_t n_cov, double* __restrict__ bands,
+    unsigned long long* __restrict__ hits, int32_t* __restrict__ fail_points,
+    int32_t* __restrict__ fail_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int n_t = 2 * n_q + 2 * n_cov;                       // requested ranks
+    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw);    // [SEL_BINS] counts
+    unsigned* slot = hist + SEL_BINS;                          // [SEL_BINS] bin -> list, or ~0u
+    double* red = reinterpret_cast<double*>(slot + SEL_BINS);  // [16] min / max per wave
+    unsigned* wsum = reinterpret_cast<unsigned*>(red + 16);    // [8] wave totals of the scan
+    unsigned* flag = wsum + 8;                                 // [0] overflow
+    unsigned* cnt = flag + 8;                                  // [n_t] members per list
+    int* tbin = reinterpret_cast<int*>(cnt + n_t);             // [n_t] bin of rank t
+    int* tk = tbin + n_t;                                      // [n_t] rank inside that bin
+    int* trank = tk + n_t;                                     // [n_t] the requested ranks
+    double* list = reinterpret_cast<double*>(
+        smem_raw + (((char*)(trank + n_t) - smem_raw + 15) & ~(size_t)15));   // [n_t][SEL_CAP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid < 2 * n_q) {
+        const int lo = q_index[tid >> 1];
+        trank[tid] = (tid & 1) ? (lo + 1 < S ? lo + 1 : S - 1) : lo;
+    } else if (tid < n_t) {
+        const int c = (tid - 2 * n_q) >> 1;
+        trank[tid] = ((tid - 2 * n_q) & 1) ? cov_hi[c] : cov_lo[c];
+    }
+
+    unsigned long long my_hits = 0;   // thread 64+c counts interval c over this workgroup's points
+    const int S_arg = S;
+    for (int64_t p = blockIdx.x; p < M; p += gridDim.x) {
+        // S is opaque inside the loop: otherwise hipcc keeps VPT clamped offsets and VPT
+        // "index < S" masks in registers across points and spills the draws themselves
+        int S = S_arg;
+        asm volatile("" : "+s"(S));
+        const double* row = R + p * S_pad;
+        double v[VPT];
+        double mn = __builtin_inf(), mx = -__builtin_inf();
+        // unconditional (clamped) loads, all in flight before the first use
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + i * SEL_THREADS;
+            v[i] = row[idx < S ? idx : S - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            if (tid + i * SEL_THREADS < S) { mn = fmin(mn, v[i]); mx = fmax(mx, v[i]); }
+        for (int b = tid; b < SEL_BINS; b += SEL_THREADS) { hist[b] = 0; slot[b] = ~0u; }
+        if (tid < n_t) cnt[tid] = 0;
+        if (tid == 0) flag[0] = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = fmin(mn, __shfl_xor(mn, o));
+            mx = fmax(mx, __shfl_xor(mx, o));
+        }
+        if (lane == 0) { red[wave] = mn; red[8 + wave] = mx; }
+        __syncthreads();
+        mn = red[0]; mx = red[8];
+#pragma unroll
+        for (int w = 1; w < SEL_THREADS / 64; ++w) { mn = fmin(mn, red[w]); mx = fmax(mx, red[8 + w]); }
+        const double scale = (double)SEL_BINS / (mx - mn);
+        // degenerate rows: every draw equal -> every rank is that value; a range too small to
+        // scale (or non-finite draws) goes to the sort
+        const bool flat = mx == mn;
+        const bool unusable = !flat && !(scale > 0.0 && scale < 1.7e308);
+        const bool usable = !flat && !unusable;
+        if (usable) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i)
+                if (tid + i * SEL_THREADS < S) atomicAdd(&hist[sel_bin(v[i], mn, scale)], 1u);
+        }
+        __syncthreads();
+        if (usable) {
+            // exclusive prefix sums over the bins, 4 consecutive bins per thread; the thread whose
+            // 4 bins contain a requested rank records its bin (no search, no second pass)
+            const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * tid);
+            const unsigned h[4] = {h4.x, h4.y, h4.z, h4.w};
+            const unsigned tot = h[0] + h[1] + h[2] + h[3];
+            unsigned inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(inc, o);
+                if (lane >= o) inc += up;
+            }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            unsigned base = inc - tot;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            for (int t = 0; t < n_t; ++t) {
+                const unsigned r = (unsigned)trank[t];
+                if (r >= base && r < base + tot) {   // exactly one thread
+                    unsigned b0 = base;
+                    int j = 0;
+                    while (r >= b0 + h[j]) { b0 += h[j]; ++j; }
+                    tbin[t] = 4 * tid + j;
+                    tk[t] = (int)(r - b0);
+                    atomicMin(&slot[4 * tid + j], (unsigned)t);
+                }
+            }
+            __syncthreads();
+            // members of the requested bins -> their lists (slot words read in one batch)
+            // (bins are recomputed, not carried in registers from the histogram pass: the
+            // opaque copy of `scale` keeps hipcc from caching VPT bin numbers and spilling)
+            double scale2 = scale;
+            asm volatile("" : "+v"(scale2));
+#pragma unroll
+            for (int i0 = 0; i0 < VPT; i0 += 8) {
+                unsigned sl[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sl[i] = slot[sel_bin(v[i0 + i], mn, scale2)];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (sl[i] != ~0u && tid + (i0 + i) * SEL_THREADS < S) {
+                        const unsigned pos = atomicAdd(&cnt[sl[i]], 1u);
+                        if (pos < SEL_CAP) list[sl[i] * SEL_CAP + pos] = v[i0 + i];
+                        else flag[0] = 1;
+                    }
+            }
+            __syncthreads();
+            if (flag[0] == 0) {
+                // one wave per list: every lane ranks its member by counting (members come from
+                // the other lanes' registers) and stores it at its rank -> the list is sorted
+                for (int t = wave; t < n_t; t += SEL_THREADS / 64) {
+                    if (slot[tbin[t]] != (unsigned)t) continue;   // not the owner of its bin
+                    const int n = (int)cnt[t];
+                    double* li = list + t * SEL_CAP;
+                    const double e = lane < n ? li[lane] : 0.0;
+                    int c = 0;
+                    for (int j = 0; j < n; ++j) {
+                        const double vj = __hiloint2double(
+                            __builtin_amdgcn_readlane(__double2hiint(e), j),
+                            __builtin_amdgcn_readlane(__double2loint(e), j));
+                        c += (vj < e || (vj == e && j < lane)) ? 1 : 0;
+                    }
+                    if (lane < n) li[c] = e;   // every lane has read its member: in-place is safe
+                }
+            }
+            __syncthreads();
+        }
+        const bool failed = unusable || (usable && flag[0] != 0);
+        if (failed) {
+            if (tid == 0) fail_points[atomicAdd(fail_count, 1)] = (int32_t)p;
+        } else {
+            // value of requested rank t: sorted list of its bin at its rank inside the bin
+            if (tid < n_q) {
+                double a = mn, b = mn;
+                if (usable) {
+                    a = list[slot[tbin[2 * tid]] * SEL_CAP + tk[2 * tid]];
+                    b = list[slot[tbin[2 * tid + 1]] * SEL_CAP + tk[2 * tid + 1]];
+                }
+                const double t = q_gamma[tid], diff = b - a;
+                bands[(int64_t)tid * M + p] = t >= 0.5 ? b - diff * (1.0 - t) : a + diff * t;
+            }
+            if (truth != nullptr && tid >= 64 && tid - 64 < n_cov) {
+                const int t0 = 2 * n_q + 2 * (tid - 64);
+                double a = mn, b = mn;
+                if (usable) {
+                    a = list[slot[tbin[t0]] * SEL_CAP + tk[t0]];
+                    b = list[slot[tbin[t0 + 1]] * SEL_CAP + tk[t0 + 1]];
+                }
+                const double y = truth[p];
+                if (a <= y && y <= b) my_hits += 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (my_hits) atomicAdd(&hits[tid - 64], my_hits);
 }
 
 hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
@@ -183,8 +380,38 @@ hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
     if (a.n_q > 0 || a.n_cov > 0) {
         int nsort = 64;
         while (nsort < a.S) nsort <<= 1;
+        // selection when there are many draws and few requested ranks, otherwise the sort
+        const int n_t = 2 * a.n_q + 2 * a.n_cov;
+        const bool select = a.S >= 2048 && a.S <= 32 * SEL_THREADS && n_t <= 128 && a.fail_points;
+        const int32_t* plist = nullptr;
+        const int32_t* pcount = nullptr;
         int64_t blocks = a.M < 2048 ? a.M : 2048;
         if (blocks < 1) blocks = 1;
+        if (select) {
+            const size_t lds = (size_t)SEL_BINS * 8 + 16 * 8 + 16 * 4 + (size_t)n_t * 16 + 16 +
+                               (size_t)n_t * SEL_CAP * 8;
+#define BMC_SEL(V)                                                                             \
+    do {                                                                                       \
+        e = hipFuncSetAttribute((const void*)predict_select_kernel<V>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (e != hipSuccess) return e;                                                         \
+        hipLaunchKernelGGL((predict_select_kernel<V>), dim3((unsigned)blocks),                 \
+                           dim3(SEL_THREADS), lds, s, (const double*)a.R, a.S, a.S_pad, a.M,   \
+                           a.q_index, a.q_gamma, a.n_q, a.truth, a.cov_lo, a.cov_hi, a.n_cov,  \
+                           a.bands, a.hits, a.fail_points, a.fail_count);                      \
+    } while (0)
+            const int vpt = (a.S + SEL_THREADS - 1) / SEL_THREADS;
+            if (vpt <= 8) BMC_SEL(8);
+            else if (vpt <= 16) BMC_SEL(16);
+            else if (vpt <= 24) BMC_SEL(24);
+            else BMC_SEL(32);
+#undef BMC_SEL
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            plist = a.fail_points;   // second pass: whatever the selection handed back
+            pcount = a.fail_count;
+            blocks = blocks < 256 ? blocks : 256;
+        }
         const size_t lds = (size_t)nsort * sizeof(double);
 #define BMC_OS(NS)                                                                            \
     do {                                                                                      \
@@ -194,7 +421,8 @@ hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((predict_orderstat_kernel<NS>), dim3((unsigned)blocks),            \
                            dim3(NS / 2 < 1024 ? (NS / 2 < 128 ? 128 : NS / 2) : 1024), lds, s, \
                            (const double*)a.R, a.S, a.S_pad, a.M, a.q_index, a.q_gamma, a.n_q, \
-                           a.truth, a.cov_lo, a.cov_hi, a.n_cov, a.bands, a.hits);            \
+                           a.truth, a.cov_lo, a.cov_hi, a.n_cov, a.bands, a.hits, plist,       \
+                           pcount);                                                            \
     } while (0)
         switch (nsort) {
             case 64: BMC_OS(64); break;

@@ -2,6 +2,8 @@
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 from pybmc_amd import _lib
+import os
+_lib.LIB_PATH = os.environ.get('BMC_LIB', _lib.LIB_PATH)
 ctx = _lib.Context(0)
 rng = np.random.default_rng(0)
 for M, Km, k in ((5000, 32, 31), (50000, 257, 256)):

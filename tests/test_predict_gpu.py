@@ -71,6 +71,38 @@ def test_replay_shapes(M, Km, k, S):
     assert np.abs(bands - want).max() < 1e-11 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("kind", ["normal", "ties", "outlier", "flat", "two_level"])
+@pytest.mark.parametrize("S", [2048, 10000, 16384])
+def test_order_statistics_by_selection_are_exact(kind, S):
+    """S >= 2048 draws: the requested ranks are found by histogram selection, and rows the
+    selection cannot resolve (a requested rank inside a bin of many equal draws, a range
+    stretched by an outlier) go through the full sort.  Either way the percentiles and coverage
+    counts are those of numpy on the returned draws, exactly."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(S + len(kind))
+    M, Km, k = 37, 3, 2
+    preds = rng.standard_normal((M, Km)) + 2
+    theta = np.column_stack([np.zeros((S, k)), np.ones(S)])          # weights 1/Km, sigma 1
+    Vt = rng.standard_normal((k, Km))
+    noise = rng.standard_normal((S, M))
+    if kind == "ties":
+        noise[: S // 2] = 0.25                      # half of every point's draws are one value
+    elif kind == "outlier":
+        noise[3] = 1e9                              # one far draw per point stretches [min, max]
+    elif kind == "flat":
+        noise[:] = -1.5                             # every draw of a point equal
+    elif kind == "two_level":
+        noise[:] = rng.integers(0, 2, size=(S, M))  # only two distinct values per point
+    truth = preds.mean(1) + rng.standard_normal(M)
+    pct = np.arange(0, 101, 5)
+    q = (2.5, 50, 97.5, 0, 100, 33.3)
+    rndm_m, bands, cov = ctx.predict(preds, theta, Vt, noise=noise, q=q, truth=truth,
+                                     cov_percentiles=pct)
+    assert np.array_equal(bands, np.percentile(rndm_m, q, axis=0))
+    df = pd.DataFrame({"truth": truth})
+    assert coverage(pct, rndm_m, df, "truth") == cov
+
+
 def test_device_generator_distribution():
     g = load_golden("predict_synth48")
     np.random.seed(3)
