@@ -69,10 +69,23 @@ def cpu_baseline(problem, budget_s=12.0, chunk=1000):
             threads = int(info[0]["num_threads"])
     except Exception:
         pass
-    return {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{done} iterations of 1 chain (N=10000, K=32, f64), numpy port of "
-                      f"reference gibbs_sampler, {el:.1f} s, BLAS threads={threads} of "
-                      f"{os.cpu_count()} host cpus"}
+    out = {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port",
+           "sample": f"{done} iterations of 1 chain (N=10000, K=32, f64), numpy port of "
+                     f"reference gibbs_sampler, {el:.1f} s, BLAS threads={threads} of "
+                     f"{os.cpu_count()} host cpus"}
+    # the same loop on one BLAS thread (SURVEY.md 8d asks for both figures), a shorter sample
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1, user_api="blas"):
+            O.gibbs_port(y, X, 20, prior)
+            d1, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < budget_s / 3:
+                O.gibbs_port(y, X, chunk, prior)
+                d1 += chunk
+            out["value_1_thread"] = d1 / (time.perf_counter() - t1)
+    except Exception:
+        pass
+    return out
 
 
 def main():
