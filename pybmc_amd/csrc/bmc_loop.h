@@ -82,6 +82,9 @@ __device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned va
         __hip_atomic_store(g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef BMC_REGMULTI_DEPTH_BIG
+#define BMC_REGMULTI_DEPTH_BIG 3
+#endif
 #ifndef BMC_POLL_DEPTH2
 #define BMC_POLL_DEPTH2 2
 #endif
@@ -276,20 +279,22 @@ struct PanelStore {
     // register residency, CPP chains per pass: u is [CPP][kpad] in LDS; per chain the operation
     // order is that of partial_rss below (four FMA chains per row, then (a0+a1)+(a2+a3)).
     // Left to itself hipcc issues all CPP*KMAX LDS reads of u before the first FMA and spills;
-    // here the address of block b's reads is made to depend (through an empty asm) on an
-    // accumulator of block b-2, so at most two blocks of UB values of u are live at a time.
+    // here the address of block b's reads is made to depend (through empty asm statements that
+    // emit no code) on the accumulators of block b-DEPTH, so at most DEPTH blocks of UB values of
+    // u are live at a time.
     template <int CPP>
     __device__ __forceinline__ void partial_rss_reg_multi(const double* u, int kpad,
                                                           double (&s)[CPP]) const {
         static_assert(MODE == MODE_REG, "register residency only");
         typedef const __attribute__((address_space(3))) double lds_cd;
-        constexpr int UB = (KMAX < 8 || KMAX * VEC * (int)sizeof(T) >= 256) ? 4 : 8;
+        // blocks of UB values of u, DEPTH blocks in flight (fewer where the panel already
+        // fills 128 VGPRs)
+        constexpr int UB = 4;
+        constexpr int DEPTH = (KMAX * VEC * (int)sizeof(T) >= 256) ? BMC_REGMULTI_DEPTH_BIG : 4;
         lds_cd* ub = (lds_cd*)u;
-        double tok1[VEC][4], tok2[VEC][4];   // the accumulators one and two blocks back
+        int tok[DEPTH];   // tok[d]: "the FMAs of the block d+1 back have been issued" (no code)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tok1[v][q] = tok2[v][q] = 0.0;
+        for (int d = 0; d < DEPTH; ++d) tok[d] = 0;
 #pragma unroll
         for (int c = 0; c < CPP; ++c) {
             double acc[PPW][VEC][4];
@@ -303,31 +308,28 @@ struct PanelStore {
 #pragma unroll
             for (int jb = 0; jb < KMAX; jb += UB) {
                 int off = c * kpad + jb;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    asm volatile("" : "+v"(off) : "v"(tok2[v][0]), "v"(tok2[v][1]), "v"(tok2[v][2]),
-                                 "v"(tok2[v][3]));
+                asm volatile("" : "+v"(off) : "v"(tok[DEPTH - 1]));
                 lds_cd* uc = ub + off;
+                const double u0 = uc[0], u1 = uc[1], u2 = uc[2], u3 = uc[3];
 #pragma unroll
-                for (int j = 0; j < UB; j += 4) {
-                    const double u0 = uc[j], u1 = uc[j + 1], u2 = uc[j + 2], u3 = uc[j + 3];
+                for (int i = 0; i < PPW; ++i)
 #pragma unroll
-                    for (int i = 0; i < PPW; ++i)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            acc[i][v][0] = fma(-as_f64_in_loop(xr[i][jb + j][v]), u0, acc[i][v][0]);
-                            acc[i][v][1] = fma(-as_f64_in_loop(xr[i][jb + j + 1][v]), u1, acc[i][v][1]);
-                            acc[i][v][2] = fma(-as_f64_in_loop(xr[i][jb + j + 2][v]), u2, acc[i][v][2]);
-                            acc[i][v][3] = fma(-as_f64_in_loop(xr[i][jb + j + 3][v]), u3, acc[i][v][3]);
-                        }
-                }
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        tok2[v][q] = tok1[v][q];
-                        tok1[v][q] = acc[PPW - 1][v][q];
+                    for (int v = 0; v < VEC; ++v) {
+                        acc[i][v][0] = fma(-as_f64_in_loop(xr[i][jb][v]), u0, acc[i][v][0]);
+                        acc[i][v][1] = fma(-as_f64_in_loop(xr[i][jb + 1][v]), u1, acc[i][v][1]);
+                        acc[i][v][2] = fma(-as_f64_in_loop(xr[i][jb + 2][v]), u2, acc[i][v][2]);
+                        acc[i][v][3] = fma(-as_f64_in_loop(xr[i][jb + 3][v]), u3, acc[i][v][3]);
                     }
+#pragma unroll
+                for (int d = DEPTH - 1; d > 0; --d) tok[d] = tok[d - 1];
+                // an output the compiler believes is made from this block's accumulators
+                int made;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    asm volatile("" : "=v"(made) : "v"(acc[PPW - 1][v][0]), "v"(acc[PPW - 1][v][1]),
+                                 "v"(acc[PPW - 1][v][2]), "v"(acc[PPW - 1][v][3]));
+                }
+                tok[0] = made;
             }
             double t = 0.0;
 #pragma unroll
