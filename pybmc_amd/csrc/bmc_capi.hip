@@ -435,7 +435,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         }
     }
     const int waves_single = geo.waves;
-    int launches = 0, cpp_used = 1;
+    int launches = 0, cpp_used = 1, waves_used = 0;
     for (int c0 = 0; iters > 0 && c0 < n_chains;) {
         const int left = n_chains - c0;
         int cpp = 1;
@@ -445,6 +445,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         a.chains_per_pass = cpp;
         if (cpp == 1) a.waves = waves_single;
         if (cpp > cpp_used) cpp_used = cpp;
+        if (a.waves > waves_used) waves_used = a.waves;
         a.xi = (const double*)c->xi.p + (size_t)c0 * T * K;
         a.gam = (const double*)c->gam.p + (size_t)c0 * T;
         a.uout = (double*)c->uout.p + (size_t)c0 * T * (K + 1);
@@ -481,7 +482,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         stats->n_chains = n_chains;
         stats->launches = launches;
         stats->groups_per_chain = geo.G;
-        stats->waves_per_group = geo.waves;
+        stats->waves_per_group = waves_used ? waves_used : geo.waves;   // widened for leader waves
         stats->chains_per_pass = cpp_used;
         stats->residency = geo.mode + 1;
         stats->xcd_local_chains = 0;

@@ -39,11 +39,14 @@ __global__ __launch_bounds__(256) void predict_weights_kernel(
 
 // --------------------------------------------------------------------- GEMM
 // Workgroup tile 64 points x 64 draws, 4 waves; wave w owns points [16w, 16w+16) x 64 draws
-// (4 MFMA tiles).  K-loop in slabs of 32 models staged through LDS with a row stride of
-// 34 doubles: a 32-lane half reads 16 rows x 2 consecutive k = banks {4r+2k, 4r+2k+1}, all
-// distinct -> conflict-free ds_read_b64.  MFMA maps (f64 form, cdna guide section 3):
-// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D: col = l&15, row = (l>>4) + 4*reg.
-constexpr int PG_KT = 32, PG_LD = 34;
+// (4 MFMA tiles).  K-loop in slabs of 16 models, double-buffered in LDS: the next slab's global
+// reads are issued before the current slab's MFMAs and written to the other buffer after
+// them, so there is one barrier per slab and the load latency sits behind the MFMAs.
+// LDS rows have a stride of 18 doubles: a 32-lane half of a ds_read_b64 reads 16 rows x 2
+// consecutive k = dword banks 36 r + 2 k (+0, +1) mod 64, all distinct -> conflict-free.
+// MFMA maps (f64 form, cdna guide section 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D: col = l&15, row = (l>>4) + 4*reg.
+constexpr int PG_KT = 16, PG_LD = 18, PG_TM = 64;
 
 __device__ __forceinline__ void pg_noise(uint64_t e, uint32_t k0, uint32_t k1, double& z0,
                                          double& z1) {
@@ -61,36 +64,58 @@ __global__ __launch_bounds__(256) void predict_gemm_kernel(
     const double* __restrict__ preds, int64_t M, int32_t Km, const double* __restrict__ Wt,
     const double* __restrict__ sig, int32_t S, int32_t S_pad, int32_t Km_pad, uint64_t seed,
     const double* __restrict__ noise_replay, double* __restrict__ R) {
-    __shared__ double As[64 * PG_LD];
-    __shared__ double Bs[64 * PG_LD];
+    __shared__ double As[2 * PG_TM * PG_LD];
+    __shared__ double Bs[2 * PG_TM * PG_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t p0 = (int64_t)blockIdx.y * 64;
-    const int32_t s0 = blockIdx.x * 64;
+    const int64_t p0 = (int64_t)blockIdx.y * PG_TM;
+    const int32_t s0 = blockIdx.x * PG_TM;
     const int cl = lane & 15, kq = lane >> 4;
     f64x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    for (int m0 = 0; m0 < Km_pad; m0 += PG_KT) {
-        for (int e = tid; e < 64 * PG_KT; e += 256) {
-            const int r = e / PG_KT, c = e % PG_KT;
+    // staging: element e = tid + 256 q of a 64 x 16 slab -> row e / 16, column e % 16
+    const int sr = tid >> 4, sc = tid & 15;    // rows sr + 16 q
+    double ra[4], rb[4];
+    auto fetch = [&](int m0) {
+        const int m = m0 + sc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sr + 16 * q;
             const int64_t p = p0 + r;
-            const int m = m0 + c;
-            As[r * PG_LD + c] = (p < M && m < Km) ? preds[p * Km + m] : 0.0;
-            Bs[r * PG_LD + c] = (m < Km_pad) ? Wt[(int64_t)(s0 + r) * Km_pad + m] : 0.0;
+            ra[q] = (p < M && m < Km) ? preds[p * Km + m] : 0.0;
+            rb[q] = (m < Km_pad) ? Wt[(int64_t)(s0 + r) * Km_pad + m] : 0.0;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = sr + 16 * q;
+            As[(buf * PG_TM + r) * PG_LD + sc] = ra[q];
+            Bs[(buf * PG_TM + r) * PG_LD + sc] = rb[q];
+        }
+    };
+
+    const int nslab = (Km_pad + PG_KT - 1) / PG_KT;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int buf = sl & 1;
+        if (sl + 1 < nslab) fetch((sl + 1) * PG_KT);
+        const double* Ab = As + (buf * PG_TM + 16 * wave + cl) * PG_LD + kq;
+        const double* Bb = Bs + (buf * PG_TM + cl) * PG_LD + kq;
 #pragma unroll
         for (int kk = 0; kk < PG_KT / 4; ++kk) {
-            const int kc = kk * 4 + kq;
-            const double a = As[(16 * wave + cl) * PG_LD + kc];
+            const double a = Ab[4 * kk];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const double b = Bs[(16 * t + cl) * PG_LD + kc];
+                const double b = Bb[16 * t * PG_LD + 4 * kk];
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
             }
         }
+        if (sl + 1 < nslab) stash(buf ^ 1);
         __syncthreads();
     }
 
@@ -371,7 +396,7 @@ hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
                            a.Vt, a.S, a.k, a.Km, a.S_pad, a.Km_pad, a.Wt, a.sig);
     }
     {
-        dim3 grid(a.S_pad / 64, (unsigned)((a.M + 63) / 64));
+        dim3 grid(a.S_pad / PG_TM, (unsigned)((a.M + PG_TM - 1) / PG_TM));
         hipLaunchKernelGGL(predict_gemm_kernel, grid, dim3(256), 0, s, a.preds, a.M, a.Km, a.Wt,
                            a.sig, a.S, a.S_pad, a.Km_pad, a.seed, a.noise_replay, a.R);
     }
