@@ -215,6 +215,17 @@ def main():
                 extra["chains8_one_gpu"] = {"samples_per_s": 8 * T / e8, "loop_ms": st8["loop_ms"],
                                             "groups_per_chain": st8["groups_per_chain"]}
                 del out8
+                # 16 chains: two per XCD, still one launch
+                seeds16 = chain_seeds(1, list(range(16)))
+                out16 = torch.empty((16, T, K + 1), dtype=torch.float64, device=dev)
+                ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
+                t1 = time.perf_counter()
+                st16 = ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
+                torch.cuda.synchronize()
+                e16 = time.perf_counter() - t1
+                extra["chains16_one_gpu"] = {"samples_per_s": 16 * T / e16, "loop_ms": st16["loop_ms"],
+                                             "launches": st16["launches"]}
+                del out16
             except Exception as e:  # never lose the headline line
                 extra["chains8_one_gpu"] = {"error": str(e)}
             try:

@@ -291,8 +291,12 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
             g.G = G;
             g.waves = waves;
             if (G <= CU_PER_XCD) {
-                g.nslot = XCD_COUNT;
-                g.chains_per_launch = n_chains < XCD_COUNT ? n_chains : XCD_COUNT;
+                // one chain per XCD; two per XCD (chains c and c + 8 share XCD c) when more than
+                // 8 chains are asked for and two groups fit a CU side by side (3 waves per
+                // SIMD at the loop kernel's register count = 12 waves per CU)
+                const int per_xcd = (n_chains > XCD_COUNT && 2 * waves <= 12) ? 2 : 1;
+                g.nslot = per_xcd * XCD_COUNT;
+                g.chains_per_launch = n_chains < g.nslot ? n_chains : g.nslot;
             } else {
                 g.chains_per_launch = MAX_GROUPS_PER_LAUNCH / G;
                 if (g.chains_per_launch > n_chains) g.chains_per_launch = n_chains;

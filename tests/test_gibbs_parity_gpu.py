@@ -456,6 +456,27 @@ def test_several_chains_per_pass(n, k, res, nch):
         assert np.abs(out[c] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
 
 
+def test_two_chains_per_xcd_when_more_than_eight_chains():
+    """One-XCD register residency with more than 8 chains: chains c and c + 8 share XCD c (two
+    workgroups per CU side by side), 16 chains per launch.  Every chain is bit-identical to the
+    same seed run alone."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(7)
+    n, k = 10000, 32
+    X = rng.standard_normal((n, k)) / np.sqrt(n)
+    y = X @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)
+    ctx.set_problem(y, X)
+    ctx.set_prior(np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+    T = 400
+    seeds = np.arange(19) + 100
+    out, st = ctx.gibbs_run(19, T, seeds=seeds)
+    assert st["residency"] == 1 and st["groups_per_chain"] <= 32
+    assert st["launches"] == 2 and st["xcd_local_chains"] in (0, 19)
+    for c in (0, 7, 8, 15, 16, 18):
+        solo, _ = ctx.gibbs_run(1, T, seeds=seeds[c:c + 1])
+        assert np.array_equal(out[c], solo[0])
+
+
 @pytest.mark.parametrize("n,k,dt,nch", [(100000, 32, np.float64, 8), (120000, 7, np.float64, 5),
                                         (200000, 64, np.float32, 8), (150000, 20, np.float32, 4)])
 def test_several_chains_per_pass_register_residency(n, k, dt, nch):
