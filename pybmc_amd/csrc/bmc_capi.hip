@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -291,12 +293,9 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
             g.G = G;
             g.waves = waves;
             if (G <= CU_PER_XCD) {
-                // one chain per XCD; two per XCD (chains c and c + 8 share XCD c) when more than
-                // 8 chains are asked for and two groups fit a CU side by side (3 waves per
-                // SIMD at the loop kernel's register count = 12 waves per CU)
-                const int per_xcd = (n_chains > XCD_COUNT && 2 * waves <= 12) ? 2 : 1;
-                g.nslot = per_xcd * XCD_COUNT;
-                g.chains_per_launch = n_chains < g.nslot ? n_chains : g.nslot;
+                // one chain per XCD (run_common widens this when more chains fit side by side)
+                g.nslot = XCD_COUNT;
+                g.chains_per_launch = n_chains < XCD_COUNT ? n_chains : XCD_COUNT;
             } else {
                 g.chains_per_launch = MAX_GROUPS_PER_LAUNCH / G;
                 if (g.chains_per_launch > n_chains) g.chains_per_launch = n_chains;
@@ -368,7 +367,26 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         if ((rc = ensure(c, c->samples, C * T * (K + 1) * 8))) return rc;
         d_samples = (double*)c->samples.p;
     }
-    const Geometry geo = choose_geometry(c, n_chains);
+    Geometry geo = choose_geometry(c, n_chains);
+    // One-XCD register residency with more than 8 chains: chains c and c + 8 share XCD c % 8 when
+    // the runtime's occupancy calculation says two of the kernel's workgroups fit one CU side by
+    // side.  (Three or four per XCD are not used: with 24 or 32 slots the launch oversubscribes
+    // the chip and the placement of workgroups on XCDs stops following blockIdx % 8.)
+    if (geo.mode == 0 && geo.G > 1 && geo.nslot == chip_of(c).xcds && n_chains > geo.nslot &&
+        c->tune.groups_per_chain <= 0) {
+        int32_t per_cu = 0;
+        GibbsArgs q{};
+        q.P = panels_of(c, c->Xrot.p);
+        q.G = geo.G; q.waves = geo.waves; q.mode = geo.mode; q.reg_ppw = geo.ppw;
+        q.nslot = geo.nslot; q.n_chains = 1; q.chains_per_pass = 1; q.panels_per_group = geo.ppg;
+        q.query_regs = &per_cu;
+        if (launch_gibbs(q, c->stream) == hipSuccess && per_cu >= 2) {
+            geo.nslot *= 2;
+            geo.chains_per_launch = n_chains < geo.nslot ? n_chains : geo.nslot;
+        }
+        if (getenv("BMC_DEBUG"))
+            fprintf(stderr, "[bmc] loop kernel: %d workgroups of %d waves per CU\n", per_cu, geo.waves);
+    }
     const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)(geo.chains_per_launch > 8 ? geo.chains_per_launch : 8) * 3 *
                                      gran_stride * 8)))
@@ -413,6 +431,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     a.force_agent_scope = c->tune.force_agent_scope;
     a.panels_per_group = geo.ppg;
     a.dbg = nullptr;
+    a.query_regs = nullptr;
 #ifdef BMC_STAMPS
     if ((rc = ensure(c, c->dbg, 12 * sizeof(long long)))) return rc;
     HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 12 * sizeof(long long), c->stream));

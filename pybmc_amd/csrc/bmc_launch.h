@@ -122,6 +122,8 @@ struct GibbsArgs {
     int32_t* placement;     // [C] out: 1 = chain verified on one XCD (L2-local exchange)
     int32_t panels_per_group;  // max panels a group owns
     long long* dbg;         // diagnostic builds only (-DBMC_STAMPS); NULL otherwise
+    int32_t* query_regs;    // host pointer; when set launch_gibbs launches nothing and reports how
+                            // many workgroups of the kernel it would have launched fit one CU
 };
 struct SimplexArgs {
     Panels P;               // UN-rotated panels (the simplex sampler proposes beta itself)

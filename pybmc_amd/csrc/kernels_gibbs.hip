@@ -522,6 +522,17 @@ struct SimplexTag {};
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
+    if (a.query_regs) {   // report, do not launch
+        int at = 0;
+        const void* fn = (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>;
+        if constexpr (MODE == MODE_REG)
+            if (a.G == 1) fn = (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>;
+        (void)at;
+        int blocks = 0;   // workgroups of this shape the runtime can keep resident per CU
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * a.waves, lds);
+        if (e == hipSuccess) *a.query_regs = blocks;
+        return e;
+    }
     if constexpr (MODE == MODE_REG) {
         if (a.G == 1) {  // the chain fits one workgroup: no exchange code at all
             hipError_t e = hipFuncSetAttribute(
@@ -707,6 +718,7 @@ static hipError_t launch_multi_reg(const GibbsArgs& a, hipStream_t s) {
 
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
     if (a.chains_per_pass > 1) {
+        if (a.query_regs) return hipErrorInvalidValue;
         // one bundle of chains_per_pass chains; needs a leader wave per chain
         if (!geometry_ok(a) || a.waves < a.chains_per_pass || a.n_chains != a.chains_per_pass)
             return hipErrorInvalidValue;

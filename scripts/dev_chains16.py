@@ -8,7 +8,7 @@ p = synth_problem(10000, 33, 32, 0)
 ctx.set_problem(p["y"], p["X"]); ctx.set_prior(*p["prior"])
 T = 20000
 ref, _ = ctx.gibbs_run(1, T, seeds=[5])
-for C in (1, 8, 16, 32):
+for C in (1, 8, 16, 24, 32):
     seeds = np.arange(C) + 1
     ctx.gibbs_run(C, 2000, seeds=seeds)
     out, st = ctx.gibbs_run(C, T, seeds=seeds)
