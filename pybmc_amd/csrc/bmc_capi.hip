@@ -6,7 +6,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -384,8 +383,6 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
             geo.nslot *= 2;
             geo.chains_per_launch = n_chains < geo.nslot ? n_chains : geo.nslot;
         }
-        if (getenv("BMC_DEBUG"))
-            fprintf(stderr, "[bmc] loop kernel: %d workgroups of %d waves per CU\n", per_cu, geo.waves);
     }
     const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)(geo.chains_per_launch > 8 ? geo.chains_per_launch : 8) * 3 *
