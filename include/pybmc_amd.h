@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PYBMC_AMD_ABI_VERSION 1
+#define PYBMC_AMD_ABI_VERSION 2
 
 typedef struct bmc_ctx bmc_ctx;
 
@@ -52,6 +52,12 @@ typedef struct {
     int32_t force_agent_scope;/* 1 = never use the XCD-local (L2) exchange     */
     int32_t chains_per_pass;  /* streamed/LDS panels: chains served by one read of X;
                                  0 auto (up to 8), 1 off, 2/4/8 cap             */
+    int32_t rss_mode;         /* 0 (default): rss = sum (y - X beta)^2 by a pass over the data
+                                 every iteration, as inference_utils.py:48-51 does.
+                                 1 (opt-in, K <= 64): the same number from sufficient statistics,
+                                 rss(u) = rss(u0) - 2 d'g0 + d'G d with d = u - u0, G = X~'X~,
+                                 g0 = X~'(y - X~ u0) and u0 the least-squares point; no pass
+                                 over the data inside the loop, one wave per chain          */
 } bmc_tuning;
 
 /* Filled by bmc_gibbs_run*.  Times are HIP-event times on the context's stream. */
@@ -66,7 +72,7 @@ typedef struct {
     int32_t groups_per_chain;
     int32_t waves_per_group;
     int32_t chains_per_pass;
-    int32_t residency;        /* 1 registers, 2 LDS, 3 streamed                */
+    int32_t residency;        /* 1 registers, 2 LDS, 3 streamed, 4 none (rss_mode 1) */
     int32_t xcd_local_chains; /* chains whose groups were verified on one XCD  */
     int64_t bytes_per_pass;   /* algorithmic: (N*K + N) * sizeof(storage)      */
     int64_t passes;           /* X passes executed in total                    */

@@ -25,7 +25,8 @@ BMC_RNG_DEVICE, BMC_RNG_REPLAY = 0, 1
 class Tuning(C.Structure):
     _fields_ = [("groups_per_chain", C.c_int32), ("waves_per_group", C.c_int32),
                 ("residency", C.c_int32), ("panels_per_wave", C.c_int32),
-                ("force_agent_scope", C.c_int32), ("chains_per_pass", C.c_int32)]
+                ("force_agent_scope", C.c_int32), ("chains_per_pass", C.c_int32),
+                ("rss_mode", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -122,7 +123,7 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.bmc_abi_version() != 1:
+        if lib.bmc_abi_version() != 2:
             raise RuntimeError("libpybmc_amd.so ABI version mismatch")
         _lib = lib
         return lib
@@ -179,11 +180,12 @@ class Context:
         self._check(self._lib.bmc_set_stream(self._h, _P(hip_stream_ptr or 0)))
 
     def set_tuning(self, groups_per_chain=0, waves_per_group=0, residency=0, panels_per_wave=0,
-                   force_agent_scope=0, chains_per_pass=0):
+                   force_agent_scope=0, chains_per_pass=0, rss_mode=0):
         """residency: 0 auto, 1 registers, 2 LDS, 3 stream from HBM; chains_per_pass: 0 auto,
-        1 off, 2/4/8 cap (streamed or LDS-pinned panels only)."""
+        1 off, 2/4/8 cap; rss_mode: 0 a pass over the data every iteration (the reference's
+        computation, default), 1 the same number from sufficient statistics (opt-in, K <= 64)."""
         t = Tuning(groups_per_chain, waves_per_group, residency, panels_per_wave,
-                   force_agent_scope, chains_per_pass)
+                   force_agent_scope, chains_per_pass, rss_mode)
         self._check(self._lib.bmc_set_tuning(self._h, C.byref(t)))
 
     # -- problem / prior ---------------------------------------------------------

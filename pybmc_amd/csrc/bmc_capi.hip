@@ -33,7 +33,7 @@ struct bmc_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    bmc_tuning tune{0, 0, 0, 0, 0, 0};
+    bmc_tuning tune{0, 0, 0, 0, 0, 0, 0};
     int n_cu = 256;
 
     // problem
@@ -47,6 +47,12 @@ struct bmc_ctx {
     std::vector<double> W, lam, c1, c2, b0;
     double nu0 = 0, s20 = 0, sigma2_init = 0;
     DevBuf dW, dWT, dLam, dC1, dC2;
+    // sufficient statistics in the rotated basis (rss_mode 1; host part made by bmc_set_prior
+    // when k <= 64, device part on first use)
+    std::vector<double> Gt, u0, g0;
+    bool have_gram_dev = false;
+    double rss0 = 0;
+    DevBuf dGt, dU0, dG0;
 
     // scratch
     DevBuf gramScratch, gramOut, rssPartial, rssOut, coef, stage, ticket;
@@ -339,6 +345,31 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
     return g;
 }
 
+// rss_mode 1: upload G, u0, g0 and take rss(u0) from ONE residual pass over the rotated panels
+int gram_device_setup(bmc_ctx* c) {
+    if (c->have_gram_dev) return BMC_OK;
+    const int k = c->k;
+    if (k > 64 || c->Gt.empty())
+        return fail(c, BMC_EINVAL, "rss_mode 1 (sufficient statistics) supports at most 64 columns");
+    int rc;
+    if ((rc = ensure(c, c->dGt, (size_t)k * k * 8)) || (rc = ensure(c, c->dU0, (size_t)k * 8)) ||
+        (rc = ensure(c, c->dG0, (size_t)k * 8)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dGt.p, c->Gt.data(), (size_t)k * k * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dU0.p, c->u0.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dG0.p, c->g0.data(), (size_t)k * 8, hipMemcpyHostToDevice, c->stream));
+    const Panels P = panels_of(c, c->Xrot.p);
+    if ((rc = ensure_ticket(c))) return rc;
+    if ((rc = ensure(c, c->rssPartial, (size_t)rss_groups(P) * 8 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->rssOut, 8 * sizeof(double)))) return rc;
+    HIPCHK(c, launch_residual_rss(P, (const double*)c->dU0.p, 1, (double*)c->rssPartial.p,
+                                  (unsigned*)c->ticket.p, (double*)c->rssOut.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->rss0, c->rssOut.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_gram_dev = true;
+    return BMC_OK;
+}
+
 int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seeds, int rng_mode,
                const double* xi, const double* g, double* samples_host, void* samples_dev,
                bmc_stats* stats) {
@@ -456,7 +487,22 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     }
     const int waves_single = geo.waves;
     int launches = 0, cpp_used = 1, waves_used = 0;
-    for (int c0 = 0; iters > 0 && c0 < n_chains;) {
+    const bool gram_mode = c->tune.rss_mode == 1;
+    if (gram_mode && iters > 0) {
+        if ((rc = gram_device_setup(c))) return rc;
+        GramArgs ga;
+        ga.k = K;
+        ga.lam = a.lam; ga.c1 = a.c1; ga.c2 = a.c2;
+        ga.Gt = (const double*)c->dGt.p; ga.u0 = (const double*)c->dU0.p; ga.g0 = (const double*)c->dG0.p;
+        ga.rss0 = c->rss0;
+        ga.nu0_s20 = a.nu0_s20; ga.sigma2_init = a.sigma2_init;
+        ga.xi = (const double*)c->xi.p; ga.gam = (const double*)c->gam.p; ga.uout = (double*)c->uout.p;
+        ga.iters = iters;
+        ga.n_chains = n_chains;
+        HIPCHK(c, launch_gibbs_gram(ga, c->stream));
+        launches = 1;
+    }
+    for (int c0 = 0; !gram_mode && iters > 0 && c0 < n_chains;) {
         const int left = n_chains - c0;
         int cpp = 1;
         while (cpp * 2 <= left && cpp * 2 <= cpp_max) cpp *= 2;
@@ -504,12 +550,13 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         stats->groups_per_chain = geo.G;
         stats->waves_per_group = waves_used ? waves_used : geo.waves;   // widened for leader waves
         stats->chains_per_pass = cpp_used;
-        stats->residency = geo.mode + 1;
+        stats->residency = gram_mode ? 4 : geo.mode + 1;
         stats->xcd_local_chains = 0;
         for (size_t i = 0; i < C; ++i) stats->xcd_local_chains += place[i] ? 1 : 0;
         stats->bytes_per_pass = ((int64_t)c->n * K + c->n) * (c->f32 ? 4 : 8);
         // a pass that serves several chains counts once
-        stats->passes = cpp_used > 1 ? (int64_t)launches * iters : (int64_t)n_chains * iters;
+        stats->passes = gram_mode ? 0 : cpp_used > 1 ? (int64_t)launches * iters : (int64_t)n_chains * iters;
+        if (gram_mode) { stats->groups_per_chain = 1; stats->waves_per_group = 1; }
     }
     for (size_t i = 0; i < C; ++i)
         if (st[i] != 0)
@@ -589,7 +636,7 @@ int bmc_set_stream(bmc_ctx* c, void* hip_stream) {
 int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
     if (!c) return BMC_EINVAL;
     if (!t) {
-        c->tune = bmc_tuning{0, 0, 0, 0, 0, 0};
+        c->tune = bmc_tuning{0, 0, 0, 0, 0, 0, 0};
         return BMC_OK;
     }
     if (t->groups_per_chain < 0 || t->groups_per_chain > 256 || t->waves_per_group < 0 ||
@@ -597,9 +644,10 @@ int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
         (t->panels_per_wave != 0 && t->panels_per_wave != 1 && t->panels_per_wave != 2 &&
          t->panels_per_wave != 4) ||
         (t->chains_per_pass != 0 && t->chains_per_pass != 1 && t->chains_per_pass != 2 &&
-         t->chains_per_pass != 4 && t->chains_per_pass != 8))
+         t->chains_per_pass != 4 && t->chains_per_pass != 8) ||
+        (t->rss_mode != 0 && t->rss_mode != 1))
         return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..8, residency 0..3, "
-                                   "panels_per_wave 0/1/2/4, chains_per_pass 0/1/2/4/8)");
+                                   "panels_per_wave 0/1/2/4, chains_per_pass 0/1/2/4/8, rss_mode 0/1)");
     c->tune = *t;
     return BMC_OK;
 }
@@ -713,6 +761,42 @@ int bmc_set_prior(bmc_ctx* c, const double* b0, const double* C0, double nu0, do
     c->b0.assign(b0, b0 + k);
     c->nu0 = nu0;
     c->s20 = sigma20;
+    // rss_mode 1 (k <= 64): G = W'AW (= diag(lam) up to rounding), the least-squares point u0 in
+    // the rotated basis and g0 = X~'(y - X~ u0) = c2 - G u0, all in extended precision
+    c->Gt.clear();
+    c->have_gram_dev = false;
+    if (k <= 64) {
+        std::vector<long double> AW((size_t)k * k, 0.0L);
+        for (int i = 0; i < k; ++i)
+            for (int m = 0; m < k; ++m) {
+                const long double aim = A[(size_t)i * k + m];
+                for (int j = 0; j < k; ++j) AW[(size_t)i * k + j] += aim * c->W[(size_t)m * k + j];
+            }
+        c->Gt.assign((size_t)k * k, 0.0);
+        std::vector<long double> Gl((size_t)k * k, 0.0L);
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                long double sum = 0.0L;
+                for (int m = 0; m < k; ++m) sum += (long double)c->W[(size_t)m * k + i] * AW[(size_t)m * k + j];
+                Gl[(size_t)i * k + j] = sum;
+            }
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j)
+                c->Gt[(size_t)i * k + j] = (double)(0.5L * (Gl[(size_t)i * k + j] + Gl[(size_t)j * k + i]));
+        double gmax = 0.0;
+        for (int j = 0; j < k; ++j) gmax = std::max(gmax, c->Gt[(size_t)j * k + j]);
+        c->u0.assign(k, 0.0);
+        for (int j = 0; j < k; ++j) {
+            const double gj = c->Gt[(size_t)j * k + j];
+            c->u0[j] = gj > 1e-14 * gmax ? c->c2[j] / gj : 0.0;
+        }
+        c->g0.assign(k, 0.0);
+        for (int i = 0; i < k; ++i) {
+            long double sum = c->c2[i];
+            for (int j = 0; j < k; ++j) sum -= (long double)c->Gt[(size_t)i * k + j] * c->u0[j];
+            c->g0[i] = (double)sum;
+        }
+    }
     std::vector<double> WT((size_t)k * k);
     for (int i = 0; i < k; ++i)
         for (int j = 0; j < k; ++j) WT[(size_t)i * k + j] = c->W[(size_t)j * k + i];

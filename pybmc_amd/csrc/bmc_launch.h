@@ -125,6 +125,25 @@ struct GibbsArgs {
     int32_t* query_regs;    // host pointer; when set launch_gibbs launches nothing and reports how
                             // many workgroups of the kernel it would have launched fit one CU
 };
+// rss from sufficient statistics (bmc_tuning.rss_mode = 1): one wave per chain, K <= 64
+struct GramArgs {
+    int32_t k;
+    const double* lam;      // [k]
+    const double* c1;       // [k]
+    const double* c2;       // [k]
+    const double* Gt;       // [k][k]  X~'X~ (symmetric)
+    const double* u0;       // [k]     centre of the expansion (least-squares point)
+    const double* g0;       // [k]     X~'(y - X~ u0)
+    double rss0;            // rss(u0), from one residual pass
+    double nu0_s20, sigma2_init;
+    const double* xi;       // [C][T][k]
+    const double* gam;      // [C][T]
+    double* uout;           // [C][T][k+1]
+    int64_t iters;
+    int32_t n_chains;
+};
+hipError_t launch_gibbs_gram(const GramArgs& a, hipStream_t s);
+
 struct SimplexArgs {
     Panels P;               // UN-rotated panels (the simplex sampler proposes beta itself)
     const double* Vt;       // [k][Km]  Vt_hat

@@ -343,6 +343,91 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
 }
 
 // ======================================================================================
+// Opt-in (bmc_tuning.rss_mode = 1, K <= 64): the same chain with rss taken from sufficient
+// statistics instead of a pass over the data.  For any centre u0,
+//     |y - X~u|^2 = |y - X~u0|^2 - 2 d'X~'(y - X~u0) + d'(X~'X~)d,      d = u - u0,
+// an identity, so with rss(u0) from one residual pass, g0 = X~'(y - X~u0) and G = X~'X~ fixed,
+// an iteration costs K^2 FMAs and touches no data.  u0 is the least-squares point, where
+// rss(u0) is smallest and both other terms vanish to first order, so nothing cancels: every
+// term is >= 0 or tiny.  One wave per chain (lane j = component j, row j of G in registers),
+// no barriers, no exchange; any number of chains per launch.  The draw u is computed with the
+// operations of gibbs_loop_kernel, so a chain differs from the data-pass chain only through
+// the rounding of rss.
+// ======================================================================================
+template <int KMAX>
+__global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
+    __shared__ double d_lds[64];
+    const int lane = threadIdx.x, K = a.k;
+    const int chain = blockIdx.x;
+    if (chain >= a.n_chains) return;
+    const int64_t T_it = a.iters;
+    const double* xi = a.xi + (int64_t)chain * T_it * K;
+    const double* gam = a.gam + (int64_t)chain * T_it;
+    double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
+    const bool act = lane < K;
+    double grow[KMAX];   // row `lane` of G
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) grow[i] = (act && i < K) ? a.Gt[(size_t)lane * K + i] : 0.0;
+    const double lam = act ? a.lam[lane] : 0.0, c1 = act ? a.c1[lane] : 0.0;
+    const double c2 = act ? a.c2[lane] : 0.0, u0 = act ? a.u0[lane] : 0.0;
+    const double g0x2 = act ? 2.0 * a.g0[lane] : 0.0;
+    d_lds[lane] = 0.0;
+    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
+    double xi_next = (act && T_it > 0) ? xi[lane] : 0.0;
+    double gam_next = T_it > 0 ? gam[0] : 1.0;
+    for (int64_t t = 0; t < T_it; ++t) {
+        // u | sigma2, the operations of gibbs_loop_kernel
+        double u = 0.0;
+        if (act) {
+            const double D = fma(lam, g_eff, sp_eff);
+            const double r = rsqrt(D);
+            const double m = fma(c2, g_eff, c1 * sp_eff);
+            u = fma(r * r, m, (sq_sp * r) * xi_next);
+        }
+        const double sp_rec = sp_eff, g_rec = g_eff;
+        const double gam_t = gam_next;
+        if (t + 1 < T_it) {
+            if (act) xi_next = xi[(t + 1) * K + lane];
+            gam_next = gam[t + 1];
+        }
+        // d -> every lane (same wave: the LDS executes its writes and reads in order)
+        const double d = u - u0;
+        d_lds[lane] = d;
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < KMAX; i += 4) {
+            acc0 = fma(grow[i], d_lds[i], acc0);
+            acc1 = fma(grow[i + 1], d_lds[i + 1], acc1);
+            acc2 = fma(grow[i + 2], d_lds[i + 2], acc2);
+            acc3 = fma(grow[i + 3], d_lds[i + 3], acc3);
+        }
+        const double gd = (acc0 + acc1) + (acc2 + acc3);
+        const double q = wave_sum(d * (gd - g0x2));
+        double rss = a.rss0 + q;
+        rss = rss > 0.0 ? rss : 0.0;
+        if (act) uout[t * (K + 1) + lane] = u;
+        if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
+        // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
+        const double scale_post = (a.nu0_s20 + rss) * 0.5;
+        const bool floor_hit = scale_post < 1e-6 * gam_t;
+        sp_eff = floor_hit ? 1e-6 : scale_post;
+        g_eff = floor_hit ? 1.0 : gam_t;
+        sq_sp = sqrt(sp_eff);
+    }
+    if (lane == 0 && T_it > 0) uout[(T_it - 1) * (K + 1) + K] = sqrt(sp_eff / g_eff);
+}
+
+hipError_t launch_gibbs_gram(const GramArgs& a, hipStream_t s) {
+    if (a.k < 1 || a.k > 64 || a.n_chains < 1) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)a.n_chains), block(64);
+    if (a.k <= 8) hipLaunchKernelGGL(gibbs_gram_kernel<8>, grid, block, 0, s, a);
+    else if (a.k <= 16) hipLaunchKernelGGL(gibbs_gram_kernel<16>, grid, block, 0, s, a);
+    else if (a.k <= 32) hipLaunchKernelGGL(gibbs_gram_kernel<32>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(gibbs_gram_kernel<64>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// ======================================================================================
 // Simplex-constrained sampler (reference pybmc/inference_utils.py:78-144): random-walk
 // Metropolis on beta with the weights beta Vt_hat + 1/Km kept on the simplex, Gibbs step
 // for sigma2.  Same machinery: the proposal's rss is the group all-reduce above.  A

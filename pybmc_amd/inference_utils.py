@@ -21,7 +21,7 @@ def _draw_seeds(n):
 
 
 def gibbs_sampler(y, X, iterations, prior_info, *, n_chains=1, seeds=None, device=0,
-                  dtype=None, return_stats=False, _problem_on_device=False):
+                  dtype=None, return_stats=False, rss="data", _problem_on_device=False):
     """Gibbs sampling for Bayesian linear regression on the GPU.
 
     Same arguments and result as the reference (inference_utils.py:4-20):
@@ -33,8 +33,12 @@ def gibbs_sampler(y, X, iterations, prior_info, *, n_chains=1, seeds=None, devic
     Extensions (keyword-only, defaults preserve the reference behaviour):
     ``n_chains`` > 1 returns ``(n_chains, iterations, k+1)``; ``seeds`` fixes the
     per-chain Philox keys; ``dtype=np.float32`` stores X and y in float32 (sums
-    stay float64).
+    stay float64); ``rss="gram"`` (opt-in, at most 64 columns) takes the residual sum of
+    squares of :48-51 from sufficient statistics instead of a pass over the data in every
+    iteration -- the same chain up to rounding of that sum, one wave per chain.
     """
+    if rss not in ("data", "gram"):
+        raise ValueError('rss must be "data" or "gram"')
     b0, C0, nu0, s20 = prior_info
     ctx = _lib.default_context(device)
     if not _problem_on_device:   # orthogonalize(method="device") left (y, X) on the GPU
@@ -42,7 +46,13 @@ def gibbs_sampler(y, X, iterations, prior_info, *, n_chains=1, seeds=None, devic
     ctx.set_prior(b0, C0, nu0, s20)
     if seeds is None:
         seeds = _draw_seeds(n_chains)
-    out, stats = ctx.gibbs_run(n_chains, int(iterations), seeds=seeds)
+    if rss == "gram":
+        ctx.set_tuning(rss_mode=1)
+    try:
+        out, stats = ctx.gibbs_run(n_chains, int(iterations), seeds=seeds)
+    finally:
+        if rss == "gram":
+            ctx.set_tuning()
     res = out[0] if n_chains == 1 else out
     return (res, stats) if return_stats else res
 

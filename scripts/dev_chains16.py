@@ -15,3 +15,4 @@ for C in (1, 8, 16, 24, 32):
     same = np.array_equal(out[4], ref[0]) if C > 4 else None
     print(C, "chains:", {k: st[k] for k in ("launches", "groups_per_chain", "waves_per_group", "xcd_local_chains")},
           f"{st['loop_ms']*1e3/T:.3f} us/iter  {C*T/st['loop_ms']/1e3:.2f} M samples/s  chain(seed 5) identical to solo: {same}", flush=True)
+
