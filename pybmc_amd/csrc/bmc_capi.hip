@@ -398,19 +398,22 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         d_samples = (double*)c->samples.p;
     }
     Geometry geo = choose_geometry(c, n_chains);
-    // One-XCD register residency with more than 8 chains: chains c and c + 8 share XCD c % 8 when
-    // the runtime's occupancy calculation says two of the kernel's workgroups fit one CU side by
-    // side.  (Three or four per XCD are not used: with 24 or 32 slots the launch oversubscribes
-    // the chip and the placement of workgroups on XCDs stops following blockIdx % 8.)
+    // One-XCD register residency with more than 8 chains: chains c and c + 8 share XCD c % 8,
+    // two workgroups per CU side by side.  That needs 4 waves per SIMD (two 5-wave groups must
+    // fit whatever SIMDs their waves land on), i.e. the kernel variant held to 128 VGPRs, which
+    // exists for light shapes only.  (Three or four per XCD are not used: measured, the launch
+    // then stalls for seconds.)
+    int pack = 0;
     if (geo.mode == 0 && geo.G > 1 && geo.nslot == chip_of(c).xcds && n_chains > geo.nslot &&
-        c->tune.groups_per_chain <= 0) {
-        int32_t per_cu = 0;
+        c->tune.groups_per_chain <= 0 && 2 * geo.waves <= 16) {
+        int32_t regs = 0;
         GibbsArgs q{};
         q.P = panels_of(c, c->Xrot.p);
         q.G = geo.G; q.waves = geo.waves; q.mode = geo.mode; q.reg_ppw = geo.ppw;
         q.nslot = geo.nslot; q.n_chains = 1; q.chains_per_pass = 1; q.panels_per_group = geo.ppg;
-        q.query_regs = &per_cu;
-        if (launch_gibbs(q, c->stream) == hipSuccess && per_cu >= 2) {
+        q.query_regs = &regs;
+        if (launch_gibbs(q, c->stream) == hipSuccess && regs > 0 && regs <= 128) {
+            pack = 1;
             geo.nslot *= 2;
             geo.chains_per_launch = n_chains < geo.nslot ? n_chains : geo.nslot;
         }
@@ -460,6 +463,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     a.panels_per_group = geo.ppg;
     a.dbg = nullptr;
     a.query_regs = nullptr;
+    a.pack = pack;
 #ifdef BMC_STAMPS
     if ((rc = ensure(c, c->dbg, 12 * sizeof(long long)))) return rc;
     HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 12 * sizeof(long long), c->stream));

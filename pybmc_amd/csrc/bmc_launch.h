@@ -122,8 +122,10 @@ struct GibbsArgs {
     int32_t* placement;     // [C] out: 1 = chain verified on one XCD (L2-local exchange)
     int32_t panels_per_group;  // max panels a group owns
     long long* dbg;         // diagnostic builds only (-DBMC_STAMPS); NULL otherwise
-    int32_t* query_regs;    // host pointer; when set launch_gibbs launches nothing and reports how
-                            // many workgroups of the kernel it would have launched fit one CU
+    int32_t* query_regs;    // host pointer; when set launch_gibbs launches nothing and reports the
+                            // VGPR count of the packed (<= 128 VGPR) variant of the kernel it
+                            // would have launched, 0 if that shape has none
+    int32_t pack;           // 1: launch the packed variant (two chains per XCD)
 };
 // rss from sufficient statistics (bmc_tuning.rss_mode = 1): one wave per chain, K <= 64
 struct GramArgs {

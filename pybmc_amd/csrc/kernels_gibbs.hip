@@ -40,8 +40,20 @@
 
 namespace bmc {
 
-template <typename T, int VEC, int MODE, int KMAX, int PPW, bool SINGLE = false>
-__global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
+// PACK: the same kernel held to 128 VGPRs (4 waves per SIMD), so that two 5-wave groups of
+// different chains fit a CU side by side whatever SIMDs their waves land on -- used when more
+// than 8 chains share a launch (two per XCD).  It exists only for shapes with one panel of at
+// most 64 data VGPRs per wave (e.g. K = 32 doubles); at 136 VGPRs the unpacked kernel is 3 %
+// faster per iteration, so a single chain keeps that one.
+template <typename T, int VEC, int MODE, int KMAX, int PPW>
+constexpr bool loop_can_pack() {
+    return MODE == MODE_REG && PPW == 1 && VEC == 1 && KMAX * (int)(sizeof(T) / 4) <= 64 &&
+           !(sizeof(T) == 4 && KMAX == 64);   // (f32, 64 columns spills at 128)
+}
+
+template <typename T, int VEC, int MODE, int KMAX, int PPW, bool SINGLE = false, bool PACK = false>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 512), amdgpu_waves_per_eu(PACK ? 4 : 2)))
+void gibbs_loop_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
     // lane-chunks of 64 columns: register residency means K <= 64, so one chunk is known at
     // compile time (fewer live registers and no dead branches in the leader's serial phase)
@@ -135,14 +147,20 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
         STAMP(1);
 
         const double gam_t = gam_next;
-        if (wave == 0 && t + 1 < T_it) {  // prefetch next iteration's variates
+        // prefetch next iteration's variates.  A single-workgroup chain has nothing long after
+        // the residual pass to hide the loads behind, so it issues them here; chains with an
+        // exchange issue them behind the pass (below).
+        auto prefetch = [&]() {
+            if (wave == 0 && t + 1 < T_it) {
 #pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = ch * 64 + lane;
-                if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
+                for (int ch = 0; ch < KCH; ++ch) {
+                    const int j = ch * 64 + lane;
+                    if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
+                }
+                gam_next = gam[t + 1];
             }
-            gam_next = gam[t + 1];
-        }
+        };
+        if constexpr (SINGLE) prefetch();
         double u_rec[KCH], sp_rec = 0.0, g_rec = 1.0;
         if (recorder) {  // copy now (wave 0 rewrites u_lds after its gather); store later
 #pragma unroll
@@ -162,6 +180,10 @@ __global__ __launch_bounds__(512) void gibbs_loop_kernel(GibbsArgs a) {
             if (__builtin_amdgcn_readfirstlane(__double2hiint(abort_late)) != 0) break;
         }
         STAMP(2);
+        // behind the residual pass: issued in front of it, hipcc made wave 0's first FMA wait
+        // for these loads (vmcnt is in-order and the panel registers were loaded "before" them
+        // as far as the loop header can tell); the exchange hides them here
+        if constexpr (!SINGLE) prefetch();
         bool got;
         const double rss = group_allreduce<SINGLE>(part, red, gr + (size_t)(t & 1) * a.gran_stride,
                                                    G, g, wave, nw, lane, epoch, local, got STAMP_ARGS);
@@ -286,14 +308,6 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         __syncthreads();  // B1
         const double abort_w = ctl[1];   // tested after the residual pass (see gibbs_loop_kernel)
         const double gam_t = gam_next;
-        if (leader && t + 1 < T_it) {
-#pragma unroll
-            for (int ch = 0; ch < KCH; ++ch) {
-                const int j = ch * 64 + lane;
-                if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
-            }
-            gam_next = gam[t + 1];
-        }
         double s[CPP];
 #pragma unroll
         for (int c = 0; c < CPP; ++c) s[c] = 0.0;
@@ -312,6 +326,15 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
             double abort_late = abort_w;
             asm volatile("" : "+v"(abort_late) : "v"(s[CPP - 1]));
             if (__builtin_amdgcn_readfirstlane(__double2hiint(abort_late)) != 0) break;
+        }
+        // next iteration's variates, behind the residual pass (see gibbs_loop_kernel)
+        if (leader && t + 1 < T_it) {
+#pragma unroll
+            for (int ch = 0; ch < KCH; ++ch) {
+                const int j = ch * 64 + lane;
+                if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
+            }
+            gam_next = gam[t + 1];
         }
         bool got;
         const double rss = group_allreduce_multi<CPP>(s, red, a.gran + (size_t)(t & 1) * a.gran_stride,
@@ -607,16 +630,27 @@ struct SimplexTag {};
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
-    if (a.query_regs) {   // report, do not launch
-        int at = 0;
-        const void* fn = (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>;
-        if constexpr (MODE == MODE_REG)
-            if (a.G == 1) fn = (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>;
-        (void)at;
-        int blocks = 0;   // workgroups of this shape the runtime can keep resident per CU
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * a.waves, lds);
-        if (e == hipSuccess) *a.query_regs = blocks;
-        return e;
+    if (a.query_regs) {   // report the packed variant's VGPR count (0: none), do not launch
+        *a.query_regs = 0;
+        if constexpr (loop_can_pack<T, VEC, MODE, KMAX, PPW>()) {
+            hipFuncAttributes at;
+            const hipError_t e = hipFuncGetAttributes(
+                &at, (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>);
+            if (e != hipSuccess) return e;
+            *a.query_regs = at.numRegs;
+        }
+        return hipSuccess;
+    }
+    if constexpr (loop_can_pack<T, VEC, MODE, KMAX, PPW>()) {
+        if (a.pack && a.G > 1) {
+            hipError_t e = hipFuncSetAttribute(
+                (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>),
+                               dim3(a.nslot * a.G), dim3(64 * a.waves), lds, s, a);
+            return hipGetLastError();
+        }
     }
     if constexpr (MODE == MODE_REG) {
         if (a.G == 1) {  // the chain fits one workgroup: no exchange code at all
