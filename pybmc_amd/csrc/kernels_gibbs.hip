@@ -103,6 +103,10 @@ void gibbs_loop_kernel(GibbsArgs a) {
     double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
     const bool recorder = (g == 0) && (wave == nw - 1);
 
+    // Every load issued so far (the panels into registers) is complete from here on, and hipcc
+    // knows it: otherwise it guards the first FMA of every iteration with s_waitcnt vmcnt(0),
+    // which makes the recording wave wait for ITS stores of the previous iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), other counters untouched
     // sigma2 = sp_eff / g_eff; starts at the OLS value (inference_utils.py:37)
     double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
     double xi_next[KCH], lam_r[KCH], c1_r[KCH], c2_r[KCH];
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
     double* u_mine = u_lds + (size_t)chain * kpad;
 
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see gibbs_loop_kernel
     double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
     double xi_next[KCH], lam_r[KCH], c1_r[KCH], c2_r[KCH];
     double gam_next = 0.0;
