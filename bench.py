@@ -283,11 +283,16 @@ def main():
             try:
                 # the persistent loop at the C4 and C5 sizes (1 chain, as on each GPU of the
                 # 8-GPU configurations); gaussian design matrices scaled to unit-norm columns
+                # ... and on a matrix larger than the 256 MiB Infinity Cache (410 MB): the streaming
+                # loop against HBM itself
                 for tag, n4, k4, dt, iters4 in (("loop_c4", 200000, 64, np.float32, 4000),
-                                                ("loop_c5", 50000, 256, np.float64, 2000)):
+                                                ("loop_c5", 50000, 256, np.float64, 2000),
+                                                ("loop_hbm", 400000, 256, np.float32, 500)):
                     rng = np.random.Generator(np.random.PCG64(8))
-                    Xl = (rng.standard_normal((n4, k4)) / np.sqrt(n4)).astype(dt)
-                    yl = (Xl.astype(np.float64) @ rng.standard_normal(k4)
+                    Xl = rng.standard_normal((n4, k4), dtype=np.float32)
+                    Xl *= np.float32(1.0 / np.sqrt(n4))
+                    Xl = Xl.astype(dt, copy=False)
+                    yl = (Xl @ rng.standard_normal(k4).astype(dt)
                           + 0.1 * rng.standard_normal(n4)).astype(dt)
                     cl = _lib.Context(local_rank)
                     cl.set_problem(yl, np.asfortranarray(Xl), dtype=dt)

@@ -25,6 +25,9 @@ struct Panels {
     int32_t vec;     // rows per lane (RP = 64*vec)
     int32_t npanels;
     int32_t f32;     // 1: T = float, 0: T = double
+    int32_t stream_keep;  // streaming loop: a group's first stream_keep panels are read with
+                          // ordinary loads (they stay in the XCD's L2 from one iteration to
+                          // the next), the others with non-temporal loads
 };
 
 // ---- set-up ----------------------------------------------------------------

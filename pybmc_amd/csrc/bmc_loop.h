@@ -172,7 +172,7 @@ __device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, i
 }
 
 // ---- partial rss of one panel, data in memory (LDS or global) ---------------------
-template <typename T, int VEC>
+template <typename T, int VEC, bool NT = false>
 __device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* __restrict__ yp,
                                             const double* __restrict__ u, int K) {
     constexpr int RP = 64 * VEC;
@@ -188,7 +188,9 @@ __device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* _
 #pragma unroll
         for (int q = 0; q < UN; ++q)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) x[q][v] = xp[(size_t)(j + q) * RP + v];
+            for (int v = 0; v < VEC; ++v)
+                x[q][v] = NT ? __builtin_nontemporal_load(&xp[(size_t)(j + q) * RP + v])
+                             : xp[(size_t)(j + q) * RP + v];
 #pragma unroll
         for (int q = 0; q < UN; q += 2) {
             const double u0 = u[j + q], u1 = u[j + q + 1];
@@ -233,9 +235,10 @@ struct PanelStore {
     const T* yg;
     T* Xs;
     T* ys;
-    int K, G, g, npl, nw, wave, lane;
+    int K, G, g, npl, nw, wave, lane, keep;
 
     __device__ __forceinline__ void init(const Panels& P, int G_, int g_, T* Xs_, T* ys_) {
+        keep = P.stream_keep;
         Xg = reinterpret_cast<const T*>(P.X);
         yg = reinterpret_cast<const T*>(P.y);
         Xs = Xs_;
@@ -382,8 +385,12 @@ struct PanelStore {
                                            ys + q * RP + lane * VEC, u_lds, K);
                 } else {
                     const int64_t p = g + (int64_t)q * G;
-                    s += panel_rss<T, VEC>(Xg + p * (int64_t)K * RP + lane * VEC,
-                                           yg + p * RP + lane * VEC, u_lds, K);
+                    if (q < keep)
+                        s += panel_rss<T, VEC>(Xg + p * (int64_t)K * RP + lane * VEC,
+                                               yg + p * RP + lane * VEC, u_lds, K);
+                    else   // streamed once per iteration: do not displace the kept panels in L2
+                        s += panel_rss<T, VEC, true>(Xg + p * (int64_t)K * RP + lane * VEC,
+                                                     yg + p * RP + lane * VEC, u_lds, K);
                 }
             }
         }
@@ -475,7 +482,7 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
 // One read of a panel column feeds CPP chains' accumulators; per chain the operation order
 // is exactly that of panel_rss, so a chain's bits do not depend on how many chains share
 // the pass.
-template <typename T, int VEC, int CPP>
+template <typename T, int VEC, int CPP, bool NT = false>
 __device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const T* __restrict__ yp,
                                                 const double* __restrict__ u, int kpad, int K,
                                                 double (&s)[CPP]) {
@@ -483,7 +490,9 @@ __device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const 
     // reads in flight per wave, bounded so that the CPP*VEC*2 accumulators and the staged
     // columns fit the 256-VGPR budget without spilling (fewer reads matter less here: with
     // many chains per pass the loop is FMA-bound, not latency-bound)
-    constexpr int UN = (64 / (CPP * VEC)) >= 16 ? 16 : (64 / (CPP * VEC)) >= 4 ? (64 / (CPP * VEC)) : 4;
+    // (one row per lane affords 16 reads in flight even with 8 chains: C5 x 8 chains 26.2 -> 23.1 us)
+    constexpr int UNB = (VEC == 1 ? 128 : 64) / (CPP * VEC);
+    constexpr int UN = UNB >= 16 ? 16 : UNB >= 4 ? UNB : 4;
     double a0[CPP][VEC], a1[CPP][VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -497,7 +506,9 @@ __device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const 
 #pragma unroll
         for (int q = 0; q < UN; ++q)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) x[q][v] = xp[(size_t)(j + q) * RP + v];
+            for (int v = 0; v < VEC; ++v)
+                x[q][v] = NT ? __builtin_nontemporal_load(&xp[(size_t)(j + q) * RP + v])
+                             : xp[(size_t)(j + q) * RP + v];
 #pragma unroll
         for (int q = 0; q < UN; q += 2)
 #pragma unroll

@@ -323,8 +323,12 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                                              store.ys + q * RP + lane * VEC, u_lds, kpad, K, s);
             } else if constexpr (MODE == MODE_STREAM) {
                 const int64_t p = g + (int64_t)q * G;
-                panel_rss_multi<T, VEC, CPP>(store.Xg + p * (int64_t)K * RP + lane * VEC,
-                                             store.yg + p * RP + lane * VEC, u_lds, kpad, K, s);
+                if (q < store.keep)
+                    panel_rss_multi<T, VEC, CPP>(store.Xg + p * (int64_t)K * RP + lane * VEC,
+                                                 store.yg + p * RP + lane * VEC, u_lds, kpad, K, s);
+                else
+                    panel_rss_multi<T, VEC, CPP, true>(store.Xg + p * (int64_t)K * RP + lane * VEC,
+                                                       store.yg + p * RP + lane * VEC, u_lds, kpad, K, s);
             }
         }
         {

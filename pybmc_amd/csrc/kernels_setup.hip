@@ -353,11 +353,30 @@ hipError_t launch_unpanelize(const double* Xp, int64_t n, int32_t k, int32_t vec
 // the partial -> the storing wave's vmcnt(0) -> agent-scope ticket add; the last
 // arriver reads every partial with agent-scope (sc1) loads.  The ticket word is
 // zero on entry and the last arriver re-zeroes it.
+template <typename T, int VEC, int NB, bool NT>
+__device__ __forceinline__ void rss_panel_columns(const T* __restrict__ xp, const double* cf, int K,
+                                                  double (&acc)[NB][VEC]) {
+    constexpr int RP = 64 * VEC;
+#pragma unroll 8
+    for (int j = 0; j < K; ++j) {
+        T xv[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            xv[v] = NT ? __builtin_nontemporal_load(&xp[(int64_t)j * RP + v]) : xp[(int64_t)j * RP + v];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double c = cf[j * NB + b];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[b][v] = fma(-(double)xv[v], c, acc[b][v]);
+        }
+    }
+}
+
 template <typename T, int VEC, int NB>
 __global__ __launch_bounds__(256) void residual_rss_kernel(
     const T* __restrict__ X, const T* __restrict__ y, int32_t K, int32_t npanels,
     const double* __restrict__ coef, int32_t nb, double* __restrict__ partial,
-    unsigned* __restrict__ ticket_word, double* __restrict__ rss) {
+    unsigned* __restrict__ ticket_word, double* __restrict__ rss, int32_t keep_panels) {
     constexpr int RP = 64 * VEC;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* cf = reinterpret_cast<double*>(smem_raw);         // [K][NB]
@@ -375,6 +394,9 @@ __global__ __launch_bounds__(256) void residual_rss_kernel(
     const int slots = gridDim.x * 4;
     for (int p = blockIdx.x * 4 + wave; p < npanels; p += slots) {
         const T* xp = X + (int64_t)p * K * RP + lane * VEC;
+        // a matrix larger than the Infinity Cache: panels past the first ~190 MB are read
+        // non-temporally, so that repeated passes keep finding the first ones cached
+        const bool nt = p >= keep_panels;
         double acc[NB][VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -382,18 +404,8 @@ __global__ __launch_bounds__(256) void residual_rss_kernel(
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[b][v] = yv;
         }
-#pragma unroll 8
-        for (int j = 0; j < K; ++j) {
-            T xv[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) xv[v] = xp[(int64_t)j * RP + v];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const double c = cf[j * NB + b];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[b][v] = fma(-(double)xv[v], c, acc[b][v]);
-            }
-        }
+        if (nt) rss_panel_columns<T, VEC, NB, true>(xp, cf, K, acc);
+        else rss_panel_columns<T, VEC, NB, false>(xp, cf, K, acc);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -455,6 +467,8 @@ template <typename T, int VEC>
 static hipError_t rss_dispatch(const Panels& P, const double* coef, int32_t nb, double* partial,
                                unsigned* ticket_word, double* rss_out, hipStream_t s) {
     const int32_t G = rss_groups(P);
+    const double panel_bytes = (double)(P.k + 1) * 64.0 * P.vec * (P.f32 ? 4 : 8);
+    const int32_t keep = panel_bytes * P.npanels > 190e6 ? (int32_t)(190e6 / panel_bytes) : P.npanels;
 #define BMC_RSS(NBV)                                                                         \
     do {                                                                                     \
         const size_t lds = ((size_t)P.k * NBV + 4 * NBV) * sizeof(double);                   \
@@ -464,7 +478,7 @@ static hipError_t rss_dispatch(const Panels& P, const double* coef, int32_t nb, 
         if (e != hipSuccess) return e;                                                       \
         hipLaunchKernelGGL((residual_rss_kernel<T, VEC, NBV>), dim3(G), dim3(256), lds, s,   \
                            (const T*)P.X, (const T*)P.y, P.k, P.npanels, coef, nb, partial,  \
-                           ticket_word, rss_out);                                            \
+                           ticket_word, rss_out, keep);                                      \
     } while (0)
     if (nb <= 1) BMC_RSS(1);
     else if (nb <= 2) BMC_RSS(2);
