@@ -276,7 +276,20 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
         }
     }
     if ((tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec <= 2) {
+        // Prefer the fewest panels per wave that keep the chain on ONE XCD (32 groups x 8 waves):
+        // its exchange is a single hop through that XCD's L2 (~0.4 us) where a chain spread over
+        // the chip pays two levels (~1.3 us), which outweighs one or three more panels per wave
+        // (~0.2 us each at K = 32); N = 30000, K = 32: 2.1 -> 1.5 us per iteration, and 8 chains
+        // then run side by side, one per XCD.
+        int first_ppw = 1;
+        if (tu.panels_per_wave <= 0 && tu.groups_per_chain <= 0 && c->vec == 1)
+            for (int ppw : {1, 2, 4})
+                if (gibbs_reg_capacity(c->k, c->f32, ppw) && (int64_t)CU_PER_XCD * 8 * ppw >= NP) {
+                    first_ppw = ppw;
+                    break;
+                }
         for (int ppw : {1, 2, 4}) {
+            if (ppw < first_ppw) continue;
             if (tu.panels_per_wave > 0 && tu.panels_per_wave != ppw) continue;
             if (c->vec == 2 && ppw != 1) continue;
             if (!gibbs_reg_capacity(c->k, c->f32, ppw * c->vec)) continue;

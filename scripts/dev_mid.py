@@ -5,7 +5,7 @@ from pybmc_amd import _lib
 ctx = _lib.Context(0)
 rng = np.random.Generator(np.random.PCG64(1))
 T = 3000
-for n, k in ((10000, 128), (20000, 100), (10000, 64), (30000, 48), (100000, 32)):
+for n, k in ((30000, 32), (60000, 16), (20000, 32), (16000, 64), (30000, 48)):
     X = rng.standard_normal((n, k)) / np.sqrt(n)
     y = X @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)
     ctx.set_problem(y, np.asfortranarray(X)); ctx.set_prior(np.zeros(k), np.eye(k) * 100.0, 1.0, 0.02)
