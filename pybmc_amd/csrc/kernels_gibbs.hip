@@ -510,7 +510,10 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
     const bool local = ctl[2] != 0.0;
     if (g == 0 && tid == 0) a.placement[0] = local ? 1 : 0;
 
-    double b_cur[MAX_KCH], b_prop[MAX_KCH], step_r[MAX_KCH], xi_next[MAX_KCH];
+    // lane-chunks of 64 columns: one, known at compile time, in register mode (K <= 64)
+    constexpr int KCH = (MODE == MODE_REG) ? 1 : MAX_KCH;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see gibbs_loop_kernel
+    double b_cur[KCH], b_prop[KCH], step_r[KCH], xi_next[KCH];
     double rss_cur = a.rss_init;                       // -log_likelihood_current (:85)
     double s2 = a.rss_init / (double)a.P.n;            // :86
     double gam_next = 0.0, unif_next = 0.5;
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
     const double w0 = 1.0 / (double)Km;
     if (wave == 0) {
 #pragma unroll
-        for (int ch = 0; ch < MAX_KCH; ++ch) {
+        for (int ch = 0; ch < KCH; ++ch) {
             const int j = ch * 64 + lane;
             b_cur[ch] = 0.0;                            // :82
             b_prop[ch] = 0.0;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
         if (wave == 0) {
             // proposal b_cur + diag(S_hat stepsize) xi  (:98,:121: mvn with a diagonal cov)
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 if (ch * 64 < K && j < K) {
                     b_prop[ch] = fma(step_r[ch], xi_next[ch], b_cur[ch]);
@@ -564,9 +567,11 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
         const bool inside = ctl[4] != 0.0;
 
         const double gam_t = gam_next;
+        // next iteration's variates (the FMAs of the residual pass do not wait for these loads:
+        // the s_waitcnt in front of the loop, see gibbs_loop_kernel)
         if (wave == 0 && t + 1 < T_tot) {
 #pragma unroll
-            for (int ch = 0; ch < MAX_KCH; ++ch) {
+            for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
                 if (ch * 64 < K && j < K) xi_next[ch] = a.xi[(t + 1) * K + j];
             }
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
                     if (iu < a.n_unif) unif_next = a.unif[iu];
                     if (uu < p_acc) {                                          // :110-112
 #pragma unroll
-                        for (int ch = 0; ch < MAX_KCH; ++ch) b_cur[ch] = b_prop[ch];
+                        for (int ch = 0; ch < KCH; ++ch) b_cur[ch] = b_prop[ch];
                         rss_cur = rss_prop;
                         if (t >= a.burn) ++accepted;
                     }
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
             if (g == 0 && t >= a.burn) {
                 double* row = a.out + (t - a.burn) * (K + 1);
 #pragma unroll
-                for (int ch = 0; ch < MAX_KCH; ++ch) {
+                for (int ch = 0; ch < KCH; ++ch) {
                     const int j = ch * 64 + lane;
                     if (ch * 64 < K && j < K) row[j] = b_cur[ch];
                 }
