@@ -195,19 +195,22 @@ int rss_on_raw(bmc_ctx* c, const double* coef_host, int32_t nb, double* out_host
     int rc;
     if ((rc = ensure_ticket(c))) return rc;
     if ((rc = ensure(c, c->rssPartial, (size_t)rss_groups(P) * 8 * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->rssOut, 8 * sizeof(double)))) return rc;
-    if ((rc = ensure(c, c->coef, (size_t)8 * c->k * sizeof(double)))) return rc;
+    // all coefficient vectors up in one copy, one launch per 8 of them back to back on the
+    // stream (the kernel re-zeroes its ticket), all results down in one copy, one sync
+    const int32_t nb8 = (nb + 7) / 8 * 8;
+    if ((rc = ensure(c, c->rssOut, (size_t)nb8 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->coef, (size_t)nb8 * c->k * sizeof(double)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->coef.p, coef_host, (size_t)nb * c->k * sizeof(double),
+                             hipMemcpyHostToDevice, c->stream));
     for (int32_t b0 = 0; b0 < nb; b0 += 8) {
         const int32_t m = nb - b0 < 8 ? nb - b0 : 8;
-        HIPCHK(c, hipMemcpyAsync(c->coef.p, coef_host + (size_t)b0 * c->k,
-                                 (size_t)m * c->k * sizeof(double), hipMemcpyHostToDevice,
-                                 c->stream));
-        HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p, m, (double*)c->rssPartial.p,
-                                      (unsigned*)c->ticket.p, (double*)c->rssOut.p, c->stream));
-        HIPCHK(c, hipMemcpyAsync(out_host + b0, c->rssOut.p, (size_t)m * sizeof(double),
-                                 hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, launch_residual_rss(P, (const double*)c->coef.p + (size_t)b0 * c->k, m,
+                                      (double*)c->rssPartial.p, (unsigned*)c->ticket.p,
+                                      (double*)c->rssOut.p + b0, c->stream));
     }
+    HIPCHK(c, hipMemcpyAsync(out_host, c->rssOut.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return BMC_OK;
 }
 
