@@ -292,6 +292,10 @@ struct PanelStore {
         typedef const __attribute__((address_space(3))) double lds_cd;
         // blocks of UB values of u, DEPTH blocks in flight (fewer where the panel already
         // fills 128 VGPRs)
+        // (Stamps: the pass is LDS-latency bound, one block of u at a time -- the volatile asm
+        // statements below are ordered against each other, so DEPTH bounds the reads in flight
+        // from above but hipcc does not use it.  Data-ordered (non-volatile) tokens let it run
+        // ahead again and spill; left as is: this mode already beats separate launches.)
         constexpr int UB = 4;
         constexpr int DEPTH = (KMAX * VEC * (int)sizeof(T) >= 256) ? BMC_REGMULTI_DEPTH_BIG : 4;
         lds_cd* ub = (lds_cd*)u;
@@ -434,8 +438,16 @@ __device__ __forceinline__ void publish_pair(gu64* gp, int g, int lane, unsigned
 // pairs.  Per step every group reads one granule per lane instead of 2G/64 registers of them,
 // and only 8 stores per step cross XCDs.  The order of summation depends on G only, never
 // on where the groups really run.
+struct NoIdleWork {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `idle` runs after this group's total is published and before the polling starts: work placed
+// there is hidden by the store -> polled-load latency the group pays anyway.
+template <typename F = NoIdleWork>
 __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g, int lane,
-                                               unsigned epoch, bool local, bool& ok STAMP_PARAMS) {
+                                               unsigned epoch, bool local, bool& ok STAMP_PARAMS,
+                                               F idle = F()) {
     // gp is opaque from here on (an offset of unknown value, so that it stays a global
     // pointer): the per-lane granule addresses are then computed where they are used instead
     // of being kept in VGPRs across the whole iteration loop
@@ -448,6 +460,7 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     gu64* gp1 = gp + gran_at(64 * team);
     if (local) publish_pair<true>(gp1, rank, lane, epoch, s);
     else publish_pair<false>(gp1, rank, lane, epoch, s);
+    idle();
     gu64 x;
     ok = granule_gather1(gp1, 2 * members, epoch, lane, x STAMP_ARGS);
     GSTAMP(5);
@@ -542,26 +555,25 @@ __device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const 
 
 // All-reduce of CPP lane partials: wave c < CPP leads chain c (sums the waves' partials of
 // its chain, publishes and gathers on that chain's granules).  Every wave calls it.
-template <int CPP>
+template <int CPP, typename F = NoIdleWork>
 __device__ __forceinline__ double group_allreduce_multi(const double (&s)[CPP], double* red,
                                                         gu64* gp_chain0, size_t chain_stride,
                                                         int G, int g, int wave, int nw, int lane,
-                                                        unsigned epoch, bool local, bool& ok) {
+                                                        unsigned epoch, bool local, bool& ok STAMP_PARAMS,
+                                                        F idle = F()) {
 #pragma unroll
     for (int c = 0; c < CPP; ++c) {
         const double t = wave_sum(s[c]);
         if (lane == 0) red[c * 8 + wave] = t;
     }
+    GSTAMP(3);
     __syncthreads();
     ok = true;
     if (wave >= CPP) return 0.0;
     const double t = sum_wave_slots(red + wave * 8, lane);
-#ifdef BMC_STAMPS
-    bool stamping = false;
-    unsigned long long acc_[12] = {}, last_ = 0;
-#endif
+    GSTAMP(4);
     return exchange_sum(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane, epoch, local,
-                        ok STAMP_ARGS);
+                        ok STAMP_ARGS, idle);
 }
 
 }  // namespace bmc

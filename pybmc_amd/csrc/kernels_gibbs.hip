@@ -292,8 +292,14 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         if (T_it > 0) gam_next = gam[0];
     }
 
+#ifdef BMC_STAMPS
+    const bool stamping = a.dbg != nullptr && blockIdx.x == 0 && wave == 0;
+    unsigned long long acc_[12] = {}, last_ = 0;
+    if (stamping) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
     for (int64_t t = 0; t < T_it; ++t) {
         const unsigned epoch = (unsigned)(t + 1);
+        GSTAMP(7);
         double u_rec[KCH];
         const double sp_rec = sp_eff, g_rec = g_eff;   // sigma2 of the previous row
         if (leader) {
@@ -310,7 +316,9 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                 }
             }
         }
+        GSTAMP(0);
         __syncthreads();  // B1
+        GSTAMP(1);
         const double abort_w = ctl[1];   // tested after the residual pass (see gibbs_loop_kernel)
         const double gam_t = gam_next;
         double s[CPP];
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                                                        store.yg + p * RP + lane * VEC, u_lds, kpad, K, s);
             }
         }
+        GSTAMP(2);
         {
             double abort_late = abort_w;
             asm volatile("" : "+v"(abort_late) : "v"(s[CPP - 1]));
@@ -346,11 +355,11 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
             gam_next = gam[t + 1];
         }
         bool got;
-        const double rss = group_allreduce_multi<CPP>(s, red, a.gran + (size_t)(t & 1) * a.gran_stride,
-                                                      chain_stride, G, g, wave, nw, lane, epoch,
-                                                      local, got);
-        if (leader) {
-            if (g == 0) {   // this chain's row t, and sigma of its previous row
+        // group 0's leaders record their chain (row t, and sigma of the previous row) between
+        // publishing and polling: the stamps showed this work, placed after the exchange, holding
+        // back group 0 -- and with it every group -- by ~1500 cycles per pass
+        auto record = [&]() {
+            if (g == 0) {
 #pragma unroll
                 for (int ch = 0; ch < KCH; ++ch) {
                     const int j = ch * 64 + lane;
@@ -358,6 +367,11 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                 }
                 if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
             }
+        };
+        const double rss = group_allreduce_multi<CPP>(s, red, a.gran + (size_t)(t & 1) * a.gran_stride,
+                                                      chain_stride, G, g, wave, nw, lane, epoch,
+                                                      local, got STAMP_ARGS, record);
+        if (leader) {
             if (!got) {
                 if (lane == 0) { ctl[1] = 1.0; a.status[chain] = 1; }
             } else {
@@ -368,7 +382,12 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                 sq_sp = sqrt(sp_eff);
             }
         }
+        GSTAMP(6);
     }
+#ifdef BMC_STAMPS
+    if (stamping && lane == 0)
+        for (int i = 0; i < 12; ++i) a.dbg[i] = (long long)acc_[i];
+#endif
     __syncthreads();
     if (leader && g == 0 && lane == 0 && T_it > 0 && ctl[1] == 0.0)
         uout[(T_it - 1) * (K + 1) + K] = sqrt(sp_eff / g_eff);
