@@ -302,7 +302,16 @@ def main():
                     stl = cl.gibbs_run_device(1, iters4, chain_seeds(1, [0]), outl.data_ptr())
                     bl = stl["bytes_per_pass"]
                     us = stl["loop_ms"] * 1e3 / iters4
+                    # the configuration's 8 chains on this one GPU (BASELINE C4 / C5 name 8 chains)
+                    it8 = max(200, iters4 // 4)
+                    out8l = torch.empty((8, it8, k4 + 1), dtype=torch.float64, device=dev)
+                    cl.gibbs_run_device(8, 100, chain_seeds(1, list(range(8))), out8l.data_ptr())
+                    st8l = cl.gibbs_run_device(8, it8, chain_seeds(1, list(range(8))), out8l.data_ptr())
+                    del out8l
                     extra[tag] = {"n_obs": n4, "k": k4, "dtype": "f32" if dt == np.float32 else "f64",
+                                  "chains8_us_per_iteration_all": st8l["loop_ms"] * 1e3 / it8,
+                                  "chains8_samples_per_s": 8 * it8 / st8l["loop_ms"] * 1e3,
+                                  "chains8_per_pass": st8l["chains_per_pass"],
                                   "us_per_iteration": us, "samples_per_s": iters4 / stl["loop_ms"] * 1e3,
                                   "algorithmic_GBs": bl / us / 1e3,
                                   "frac_of_8TBs": bl / us / 1e3 / HBM_PEAK_GBS,
