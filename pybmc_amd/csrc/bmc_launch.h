@@ -12,9 +12,10 @@ namespace bmc {
 #endif
 constexpr int GRAN_PAIR_STRIDE = BMC_GRAN_PAIR_STRIDE;
 // u64 words of one (chain, parity) exchange slot: G <= 32 groups use pairs 0..G-1; larger
-// chains use 8 team areas of 32 pairs and 8 team-total pairs (bmc_loop.h, exchange_sum)
+// chains use 8 team areas of 32 pairs, 8 team-total pairs and 8 relay pairs (bmc_loop.h,
+// exchange_sum)
 inline int gran_slot_words(int G) {
-    return (G <= 32 ? ((2 * G + 31) / 32) * 16 : 256 + 8) * GRAN_PAIR_STRIDE;
+    return (G <= 32 ? ((2 * G + 31) / 32) * 16 : 256 + 8 + 8) * GRAN_PAIR_STRIDE;
 }
 
 struct Panels {

@@ -444,7 +444,12 @@ struct NoIdleWork {
 
 // `idle` runs after this group's total is published and before the polling starts: work placed
 // there is hidden by the store -> polled-load latency the group pays anyway.
-template <typename F = NoIdleWork>
+// RELAY (passes that serve several chains): only the first member of each team polls the 8 team
+// totals at agent scope; it then hands the chain total to its team through the team's XCD-local
+// area (pair 264 + team), which the other members poll.  One more local hop, but 8 agent-scope
+// pollers per chain instead of G: with 8 chains per pass the agent-scope polls of 8 x 196 waves
+// made the second level 3.5x slower than it is for one chain (stamps, dev_stamps_multi.py).
+template <bool RELAY = false, typename F = NoIdleWork>
 __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g, int lane,
                                                unsigned epoch, bool local, bool& ok STAMP_PARAMS,
                                                F idle = F()) {
@@ -467,9 +472,19 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     double tot = ok ? granule_sum1(x, lane) : 0.0;
     if (teams && ok) {
         gu64* gp2 = gp + gran_at(2 * 256);
+        gu64* gp3 = gp + gran_at(2 * (264 + team));
         if (rank == 0) publish_pair<false>(gp2, team, lane, epoch, tot);
-        ok = granule_gather1<BMC_POLL_DEPTH2>(gp2, 16, epoch, lane, x STAMP_ARGS);
-        tot = ok ? granule_sum1(x, lane) : 0.0;
+        if (!RELAY || rank == 0) {
+            ok = granule_gather1<BMC_POLL_DEPTH2>(gp2, 16, epoch, lane, x STAMP_ARGS);
+            tot = ok ? granule_sum1(x, lane) : 0.0;
+            if (RELAY && ok) {
+                if (local) publish_pair<true>(gp3, 0, lane, epoch, tot);
+                else publish_pair<false>(gp3, 0, lane, epoch, tot);
+            }
+        } else {
+            ok = granule_gather1(gp3, 2, epoch, lane, x STAMP_ARGS);
+            tot = ok ? granule_sum1(x, lane) : 0.0;   // the relayed double itself (+ zeros)
+        }
     }
     GSTAMP(8);
     return tot;
@@ -488,7 +503,7 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
     s = sum_wave_slots(red, lane);
     GSTAMP(4);
     if constexpr (SINGLE) return s;
-    return exchange_sum(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS);
+    return exchange_sum<false>(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS);
 }
 
 // ---- several chains per pass (streaming / LDS residency) ---------------------------------
@@ -572,8 +587,8 @@ __device__ __forceinline__ double group_allreduce_multi(const double (&s)[CPP], 
     if (wave >= CPP) return 0.0;
     const double t = sum_wave_slots(red + wave * 8, lane);
     GSTAMP(4);
-    return exchange_sum(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane, epoch, local,
-                        ok STAMP_ARGS, idle);
+    return exchange_sum<(CPP >= 4)>(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane, epoch,
+                                    local, ok STAMP_ARGS, idle);
 }
 
 }  // namespace bmc
