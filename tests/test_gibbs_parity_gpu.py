@@ -391,6 +391,13 @@ def test_residual_kernel_properties_at_full_size():
     got = ctx.residual_rss(B)
     want = np.array([yty - 2 * b @ c + b @ A @ b for b in B])
     assert np.abs(got - want).max() < 1e-10 * yty
+    # more vectors than one launch takes (8): launches back to back, one copy each way; every
+    # vector's result is that of asking for it alone
+    B = rng.standard_normal((21, k)) * 0.1
+    many = ctx.residual_rss(B)
+    assert many.shape == (21,)
+    for i in (0, 7, 8, 15, 16, 20):
+        assert many[i] == ctx.residual_rss(B[i])[0]
     assert np.abs(np.linalg.eigvalsh(A)).min() > 0 and np.allclose(A, A.T, rtol=0, atol=0)
 
 
