@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpybmc_amd.so")
 
+ABI_VERSION = 2   # PYBMC_AMD_ABI_VERSION of include/pybmc_amd.h this binding was written for
 BMC_OK, BMC_EINVAL, BMC_ESINGULAR, BMC_EHIP, BMC_ENOMEM, BMC_ETIMEOUT, BMC_ESTATE = range(7)
 BMC_F64, BMC_F32 = 0, 1
 BMC_ROW_MAJOR, BMC_COL_MAJOR = 0, 1
@@ -123,7 +124,7 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.bmc_abi_version() != 2:
+        if lib.bmc_abi_version() != ABI_VERSION:
             raise RuntimeError("libpybmc_amd.so ABI version mismatch")
         _lib = lib
         return lib
