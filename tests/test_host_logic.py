@@ -121,3 +121,21 @@ def test_posterior_summary_weights_sum_to_one():
     s = posterior_summary(g["samples"], Vt_hat)
     assert abs(s["weights_mean"].sum() - 1.0) < 1e-12
     assert s["beta_mean"].shape == (3,)
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_host():
+    """bench.py's cpu_baseline (the numpy port of the reference loop, the only thing in bench.py
+    that may use oracle/) on a tiny problem and a tiny time budget: the fields the judge reads."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    from pybmc_amd.synthetic import synth_problem
+    p = synth_problem(400, 5, 4, 0)
+    out = bench.cpu_baseline(p, budget_s=0.3, chunk=50)
+    assert out["kind"] == "port" and out["unit"] == "samples/s" and out["value"] > 0
+    assert out["cores"] >= 1 and "iterations" in out["sample"]
+    assert out.get("value_1_thread", 1.0) > 0
