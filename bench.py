@@ -70,7 +70,7 @@ def cpu_baseline(problem, budget_s=12.0, chunk=1000):
     except Exception:
         pass
     out = {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port",
-           "sample": f"{done} iterations of 1 chain (N=10000, K=32, f64), numpy port of "
+           "sample": f"{done} iterations of 1 chain (N={X.shape[0]}, K={X.shape[1]}, f64), numpy port of "
                      f"reference gibbs_sampler, {el:.1f} s, BLAS threads={threads} of "
                      f"{os.cpu_count()} host cpus"}
     # the same loop on one BLAS thread (SURVEY.md 8d asks for both figures), a shorter sample
