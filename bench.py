@@ -9,10 +9,17 @@ variate generation, the persistent loop kernel, the un-rotation of the draws --
 and, for N > 1, the one RCCL all-gather that pools the chains.  X, y and the prior
 are resident in HBM before the timed region starts.  Weak scaling: one chain per
 GPU by default (BASELINE.json configs[1] at N=1, configs[2] at N=8).
+
+Launching.  ``--gpus N`` with N > 1 needs N ranks.  Under ``torch.distributed.run``
+(WORLD_SIZE in the environment) this process IS one rank.  Started plainly, it becomes a
+parent that never touches the GPU, starts N fresh rank children of itself on 127.0.0.1 and
+relays rank 0's JSON line, so ``python bench.py --gpus 8`` works as it stands.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,9 +29,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+NOMINAL_CLOCK_GHZ = 2.4      # max shader clock, same guide
+F64_VECTOR_TFLOPS = 78.6     # whole chip (256 CUs); one XCD = 1/8
+PINGPONG_ONE_WAY_CYCLES = 640   # scripts/micro/pingpong.hip: store -> polled load, one XCD's L2
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=50000)
+    ap.add_argument("--chains-per-gpu", type=int, default=1)
+    ap.add_argument("--n-obs", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--groups", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--rank-timeout-s", type=float, default=1500.0,
+                    help="self-spawned ranks are stopped after this long")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="rehearse the launch / rendezvous / pooling plumbing on the CPU with "
+                         "gloo and a stand-in for the sampler; measures nothing")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------- launching
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """Parent of a plain ``python bench.py --gpus N``: start N rank children (fresh
+    interpreters, one per GPU), relay rank 0's stdout, exit with the worst return code.
+    The parent imports neither torch nor the HIP library."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=env, stdout=out, stderr=None, cwd=ROOT))
+    deadline = time.monotonic() + args.rank_timeout_s
+    rc = 0
+    line = b""
+    try:
+        line, _ = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.monotonic()))
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:      # exactly the children started above, by PID
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    sys.stdout.write(line.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------- helpers
 def profiled_traffic(kernel_substr):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary
     (profiles/rNN_summary.json, FETCH_SIZE/WRITE_SIZE collected in separate passes and
@@ -85,24 +160,52 @@ def cpu_baseline(problem, budget_s=12.0, chunk=1000):
             out["value_1_thread"] = d1 / (time.perf_counter() - t1)
     except Exception:
         pass
+    # any GPU / CPU ratio is to be read against the FASTER of the two host figures
+    out["best_value"] = max(out["value"], out.get("value_1_thread", 0.0))
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=50000)
-    ap.add_argument("--chains-per-gpu", type=int, default=1)
-    ap.add_argument("--n-obs", type=int, default=10000)
-    ap.add_argument("--k", type=int, default=32)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--groups", type=int, default=0)
-    ap.add_argument("--waves", type=int, default=0)
-    args = ap.parse_args()
+class DryRunCtx:
+    """--dry-run-cpu only: stands where pybmc_amd._lib.Context stands so that the launch,
+    rendezvous and pooling code of this file and of pybmc_amd.chains can be rehearsed on a
+    machine without a GPU (gloo).  It samples nothing: every chain's block is filled with a
+    function of its seed.  Never used by a measurement."""
 
+    def __init__(self, k):
+        import torch
+        self.k, self.device, self.torch_device = k, 0, torch.device("cpu")
+        self.calls = 0
+
+    def gibbs_run_device(self, n_chains, iters, seeds, out_ptr):
+        import ctypes
+        n = n_chains * iters * (self.k + 1)
+        buf = np.ctypeslib.as_array((ctypes.c_double * n).from_address(out_ptr))
+        buf = buf.reshape(n_chains, iters, self.k + 1)
+        t = np.arange(iters)[:, None]
+        j = np.arange(self.k + 1)[None, :]
+        for c, s in enumerate(np.asarray(seeds, dtype=np.uint64)):
+            buf[c] = (int(s) % 1000003) * 1e-3 + t + 1e-3 * j + self.calls
+        self.calls += 1
+        return {"loop_ms": 0.0, "passes": n_chains * iters, "bytes_per_pass": 0,
+                "chains_per_pass": 1, "groups_per_chain": 0, "waves_per_group": 0,
+                "residency": 0, "xcd_local_chains": 0}
+
+
+def device_label(torch, idx):
+    p = torch.cuda.get_device_properties(idx)
+    parts = [p.name]
+    if hasattr(p, "pci_bus_id"):
+        parts.append("pci %04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id,
+                                             getattr(p, "pci_device_id", 0)))
+    if hasattr(p, "uuid"):
+        parts.append(f"uuid {p.uuid}")
+    if hasattr(p, "gcnArchName"):
+        parts.append(p.gcnArchName)
+    return ", ".join(str(x) for x in parts)
+
+
+# ------------------------------------------------------------------------- one rank
+def rank_main(args):
     import torch  # first: the HIP runtime torch ships must be the one in the process
     import torch.distributed as dist
 
@@ -110,38 +213,56 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    dry = args.dry_run_cpu
+    backend = "gloo" if dry else "nccl"
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
 
-    from pybmc_amd import _lib
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     from pybmc_amd.chains import chain_block, chain_seeds, pool_samples
-    from pybmc_amd.synthetic import synth_problem
 
     N, K, T, cpg = args.n_obs, args.k, args.iters, args.chains_per_gpu
-    prob = synth_problem(N, K + 1, K, seed=0)
-    ctx = _lib.Context(local_rank)
-    ctx.set_problem(prob["y"], prob["X"])              # X, y -> HBM (outside the timed region)
-    ctx.set_prior(*prob["prior"])
-    if args.groups or args.waves:
-        ctx.set_tuning(args.groups, args.waves)
+    prob = None
+    if dry:
+        ctx = DryRunCtx(K)
+    else:
+        from pybmc_amd import _lib
+        from pybmc_amd.synthetic import synth_problem
+        prob = synth_problem(N, K + 1, K, seed=0)
+        ctx = _lib.Context(local_rank)
+        ctx.set_problem(prob["y"], prob["X"])              # X, y -> HBM (outside the timed region)
+        ctx.set_prior(*prob["prior"])
+        if args.groups or args.waves:
+            ctx.set_tuning(args.groups, args.waves)
     n_chains = world * cpg
     mine = chain_block(n_chains, world, rank)
     seeds = chain_seeds(1, mine)
     out = torch.empty((len(mine), T, K + 1), dtype=torch.float64, device=dev)
 
-    loop_ms, bytes_moved = [], []
+    loop_ms, bytes_moved, gather_ms = [], [], []
 
     def step(record):
         st = ctx.gibbs_run_device(len(mine), T, seeds, out.data_ptr())
         pooled = out
         if world > 1:
-            pooled = pool_samples(out, n_chains)
-            torch.cuda.synchronize()   # the all-gather has read `out` before the next step rewrites it
+            t_g = time.perf_counter()
+            pooled = pool_samples(out, n_chains)   # returns once the collective has read `out`
+            sync()
+            if record:
+                gather_ms.append((time.perf_counter() - t_g) * 1e3)
         if record:
             loop_ms.append(st["loop_ms"])
             bytes_moved.append(st["passes"] * st["bytes_per_pass"] / max(st["chains_per_pass"], 1))
@@ -151,11 +272,11 @@ def main():
         st, pooled = step(False)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st, pooled = step(True)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -164,22 +285,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # sanity on the last pooled block: finite and centred on the generating coefficients
-    host = pooled[:, T // 5:, :].mean(dim=(0, 1)).cpu().numpy()
-    assert np.isfinite(host).all()
-    assert abs(host[-1] - 0.1) < 0.01, f"posterior sigma {host[-1]} is off the generating 0.1"
+    # what every rank reports about itself (gathered on rank 0 for the JSON line)
+    mine_info = {"rank": rank, "device": "cpu (dry run)" if dry else device_label(torch, local_rank),
+                 "loop_ms": float(np.mean(loop_ms)) if loop_ms else 0.0,
+                 "allgather_ms": float(np.mean(gather_ms)) if gather_ms else 0.0}
+    infos = [mine_info]
+    if world > 1:
+        infos = [None] * world
+        dist.all_gather_object(infos, mine_info)
+
+    if dry:
+        # the pooled block must hold every global chain's stand-in values, in chain order
+        want = chain_seeds(1, list(range(n_chains)))
+        got = pooled[:, 0, 0].numpy() - (ctx.calls - 1)
+        assert np.allclose(got, [(int(s) % 1000003) * 1e-3 for s in want]), "pooling order broken"
+    else:
+        # sanity on the last pooled block: finite and centred on the generating coefficients
+        host = pooled[:, T // 5:, :].mean(dim=(0, 1)).cpu().numpy()
+        assert np.isfinite(host).all()
+        assert abs(host[-1] - 0.1) < 0.01, f"posterior sigma {host[-1]} is off the generating 0.1"
 
     if rank == 0:
         total_samples = n_chains * T * args.steps
         value = total_samples / elapsed
         avg_loop_ms = float(np.mean(loop_ms))
-        achieved = float(np.mean(bytes_moved)) / (avg_loop_ms * 1e-3) / 1e9
         line = {
             "metric": "Gibbs samples/sec (all chains) at N_obs=10k, K=32",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "value": None if dry else value, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "none (dry run of the launch plumbing)" if dry else "synthetic",
             "config": {"workload": f"C2: synthetic N_obs={N}, K={K}, f64, {cpg} chain/GPU x {T} "
                                    f"iterations per step, 1 RCCL all-gather per step when N>1",
                        "n_obs": N, "k": K, "iters_per_step": T, "chains_per_gpu": cpg,
@@ -188,145 +323,239 @@ def main():
                        "waves_per_group": st["waves_per_group"],
                        "residency": {1: "vgpr", 2: "lds", 3: "stream"}.get(st["residency"]),
                        "xcd_local_exchange": bool(st["xcd_local_chains"])},
-            "roofline": {"bound": "hbm", "kernel": "gibbs_loop_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (profiled_traffic("gibbs_loop_kernel") or {}).get(
-                             "bytes_per_launch"),
-                         "traffic_source": (profiled_traffic("gibbs_loop_kernel") or {}).get("source"),
-                         "algorithmic_bytes_per_launch": float(np.mean(bytes_moved)),
-                         "note": "achieved = algorithmic bytes ((N*K+N)*8 per iteration x "
-                                 "iterations) / HIP-event time of the loop kernel; at this size "
-                                 "the row panels stay in VGPRs for the whole launch, so the HBM "
-                                 "traffic (variates in, draws out) is far below the algorithmic "
-                                 "bytes and the binding limit is per-iteration latency (DESIGN.md)",
-                         "loop_ms_per_launch": avg_loop_ms,
-                         "us_per_iteration": avg_loop_ms * 1e3 / T},
         }
-        if world == 1 and not args.no_extra:
-            extra = {}
-            try:
-                seeds8 = chain_seeds(1, list(range(8)))
-                out8 = torch.empty((8, T, K + 1), dtype=torch.float64, device=dev)
-                ctx.gibbs_run_device(8, T, seeds8, out8.data_ptr())
-                t1 = time.perf_counter()
-                st8 = ctx.gibbs_run_device(8, T, seeds8, out8.data_ptr())
-                torch.cuda.synchronize()
-                e8 = time.perf_counter() - t1
-                extra["chains8_one_gpu"] = {"samples_per_s": 8 * T / e8, "loop_ms": st8["loop_ms"],
-                                            "groups_per_chain": st8["groups_per_chain"]}
-                del out8
-                # 16 chains: two per XCD, still one launch
-                seeds16 = chain_seeds(1, list(range(16)))
-                out16 = torch.empty((16, T, K + 1), dtype=torch.float64, device=dev)
-                ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
-                t1 = time.perf_counter()
-                st16 = ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
-                torch.cuda.synchronize()
-                e16 = time.perf_counter() - t1
-                extra["chains16_one_gpu"] = {"samples_per_s": 16 * T / e16, "loop_ms": st16["loop_ms"],
-                                             "launches": st16["launches"]}
-                del out16
-            except Exception as e:  # never lose the headline line
-                extra["chains8_one_gpu"] = {"error": str(e)}
-            try:
-                # opt-in, reported separately: rss from sufficient statistics
-                # instead of the per-iteration pass over the data that the headline measures
-                ctx.set_tuning(rss_mode=1)
-                og = {}
-                for cg in (1, 256):
-                    outg = torch.empty((cg, T, K + 1), dtype=torch.float64, device=dev)
-                    sg = chain_seeds(1, list(range(cg)))
-                    ctx.gibbs_run_device(cg, T, sg, outg.data_ptr())
-                    stg = ctx.gibbs_run_device(cg, T, sg, outg.data_ptr())
-                    og[f"chains{cg}"] = {"samples_per_s": cg * T / (stg["loop_ms"] * 1e-3),
-                                         "us_per_iteration": stg["loop_ms"] * 1e3 / T}
-                    del outg
-                og["note"] = ("NOT the headline path: no pass over X inside the loop "
-                              "(rss(u) = rss(u0) - 2 d'g0 + d'Gd, K <= 64), one wave per chain")
-                extra["opt_in_rss_from_sufficient_statistics"] = og
-            except Exception as e:
-                extra["opt_in_rss_from_sufficient_statistics"] = {"error": str(e)}
-            finally:
-                ctx.set_tuning()
-            try:
-                # residual-reduction kernel at the C4 size (N=200000, K=64, f32 storage)
-                rng = np.random.Generator(np.random.PCG64(4))
-                X4 = np.asfortranarray(rng.standard_normal((200000, 64), dtype=np.float32))
-                y4 = rng.standard_normal(200000, dtype=np.float32)
-                c4 = _lib.Context(local_rank)
-                c4.set_problem(y4, X4, dtype=np.float32)
-                ms = c4.residual_rss_bench(nb=1, reps=50)
-                b4 = (200000 * 64 + 200000) * 4
-                extra["residual_rss_c4"] = {"ms_per_pass": ms, "achieved_GBs": b4 / (ms * 1e-3) / 1e9,
-                                            "frac_of_8TBs": b4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "bytes_per_pass": b4,
-                                            "note": "52 MB working set: served by the 256 MiB "
-                                                    "Infinity Cache after the first pass"}
-                del X4, y4
-                # the same kernel on a working set that cannot stay in the Infinity Cache
-                nbig = 2_000_000
-                Xb = np.asfortranarray(rng.standard_normal((nbig, 64), dtype=np.float32))
-                yb = rng.standard_normal(nbig, dtype=np.float32)
-                c4.set_problem(yb, Xb, dtype=np.float32)
-                ms = c4.residual_rss_bench(nb=1, reps=20)
-                bb = (nbig * 64 + nbig) * 4
-                extra["residual_rss_hbm"] = {"n_obs": nbig, "k": 64, "dtype": "f32",
-                                             "ms_per_pass": ms,
-                                             "achieved_GBs": bb / (ms * 1e-3) / 1e9,
-                                             "frac_of_8TBs": bb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "bytes_per_pass": bb,
-                                             "note": "520 MB per pass > 256 MiB Infinity Cache: HBM-served"}
-                del Xb, yb
-                c4.close()
-            except Exception as e:
-                extra["residual_rss_c4"] = {"error": str(e)}
-            try:
-                # the persistent loop at the C4 and C5 sizes (1 chain, as on each GPU of the
-                # 8-GPU configurations); gaussian design matrices scaled to unit-norm columns
-                # ... and on a matrix larger than the 256 MiB Infinity Cache (410 MB): the streaming
-                # loop against HBM itself
-                for tag, n4, k4, dt, iters4 in (("loop_c4", 200000, 64, np.float32, 4000),
-                                                ("loop_c5", 50000, 256, np.float64, 2000),
-                                                ("loop_hbm", 400000, 256, np.float32, 500)):
-                    rng = np.random.Generator(np.random.PCG64(8))
-                    Xl = rng.standard_normal((n4, k4), dtype=np.float32)
-                    Xl *= np.float32(1.0 / np.sqrt(n4))
-                    Xl = Xl.astype(dt, copy=False)
-                    yl = (Xl @ rng.standard_normal(k4).astype(dt)
-                          + 0.1 * rng.standard_normal(n4)).astype(dt)
-                    cl = _lib.Context(local_rank)
-                    cl.set_problem(yl, np.asfortranarray(Xl), dtype=dt)
-                    cl.set_prior(np.zeros(k4), np.eye(k4) * 100.0, 1.0, 0.02)
-                    outl = torch.empty((1, iters4, k4 + 1), dtype=torch.float64, device=dev)
-                    cl.gibbs_run_device(1, 200, chain_seeds(1, [0]), outl.data_ptr())
-                    stl = cl.gibbs_run_device(1, iters4, chain_seeds(1, [0]), outl.data_ptr())
-                    bl = stl["bytes_per_pass"]
-                    us = stl["loop_ms"] * 1e3 / iters4
-                    # the configuration's 8 chains on this one GPU (BASELINE C4 / C5 name 8 chains)
-                    it8 = max(200, iters4 // 4)
-                    out8l = torch.empty((8, it8, k4 + 1), dtype=torch.float64, device=dev)
-                    cl.gibbs_run_device(8, 100, chain_seeds(1, list(range(8))), out8l.data_ptr())
-                    st8l = cl.gibbs_run_device(8, it8, chain_seeds(1, list(range(8))), out8l.data_ptr())
-                    del out8l
-                    extra[tag] = {"n_obs": n4, "k": k4, "dtype": "f32" if dt == np.float32 else "f64",
-                                  "chains8_us_per_iteration_all": st8l["loop_ms"] * 1e3 / it8,
-                                  "chains8_samples_per_s": 8 * it8 / st8l["loop_ms"] * 1e3,
-                                  "chains8_per_pass": st8l["chains_per_pass"],
-                                  "us_per_iteration": us, "samples_per_s": iters4 / stl["loop_ms"] * 1e3,
-                                  "algorithmic_GBs": bl / us / 1e3,
-                                  "frac_of_8TBs": bl / us / 1e3 / HBM_PEAK_GBS,
-                                  "residency": {1: "vgpr", 2: "lds", 3: "stream"}.get(stl["residency"]),
-                                  "groups": stl["groups_per_chain"], "waves": stl["waves_per_group"]}
-                    del outl, Xl, yl
-                    cl.close()
-            except Exception as e:
-                extra["loop_c4"] = {"error": str(e)}
-            line["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(prob)
+        if dry:
+            line["dry_run"] = True
+        line["rccl"] = {
+            "world": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else "none (single rank: no collective)"),
+            "devices": [i["device"] for i in infos],
+            "allgather_bytes_per_rank": len(mine) * T * (K + 1) * 8,
+            "allgather_ms": max(i["allgather_ms"] for i in infos),
+            "allgather_ms_per_rank": [i["allgather_ms"] for i in infos],
+            "loop_ms_min": min(i["loop_ms"] for i in infos),
+            "loop_ms_max": max(i["loop_ms"] for i in infos),
+        }
+        if not dry:
+            line["roofline"] = roofline_entry(st, avg_loop_ms, float(np.mean(bytes_moved)), N, K, T)
+            if world == 1 and not args.no_extra:
+                line["extra"] = extras(ctx, torch, dev, local_rank, N, K, T)
+            if world == 1 and not args.no_cpu_baseline:
+                cb = cpu_baseline(prob, budget_s=args.cpu_budget_s)
+                line["cpu_baseline"] = cb
+                line["gpu_over_cpu_best"] = value / cb["best_value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def roofline_entry(st, avg_loop_ms, alg_bytes, N, K, T):
+    """The dominant kernel's line.  ``achieved`` is SURVEY 8(d)'s algorithmic bytes
+    ((N*K+N)*8 per iteration x iterations) over the loop kernel's HIP-event time.  What binds
+    the kernel depends on where the panels live: streamed from HBM -> "hbm"; resident in
+    VGPRs / LDS -> the per-iteration dependency chain ("latency"): the bytes are then never
+    moved, and ``frac`` is NOT an HBM utilisation -- the latency figures below are what to read."""
+    achieved = alg_bytes / (avg_loop_ms * 1e-3) / 1e9
+    residency = {1: "vgpr", 2: "lds", 3: "stream"}.get(st["residency"])
+    us_it = avg_loop_ms * 1e3 / T
+    tr = profiled_traffic("gibbs_loop_kernel") or {}
+    traffic = tr.get("bytes_per_launch")
+    r = {"bound": "hbm" if residency == "stream" else "latency", "kernel": "gibbs_loop_kernel",
+         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": tr.get("source"),
+         "algorithmic_bytes_per_launch": alg_bytes,
+         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+         "loop_ms_per_launch": avg_loop_ms, "us_per_iteration": us_it, "residency": residency}
+    if residency != "stream":
+        xcds = 1 if st["xcd_local_chains"] else 8
+        flops_it = 2.0 * N * K + 3.0 * N
+        r["latency"] = {
+            "cycles_per_iteration_at_2.4GHz": us_it * NOMINAL_CLOCK_GHZ * 1e3,
+            "exchange_floor_cycles_one_way": PINGPONG_ONE_WAY_CYCLES,
+            "exchange_floor_source": "scripts/micro/pingpong.hip (store -> polled load through one XCD's L2)",
+            "xcds_used": xcds,
+            "f64_fma_frac_of_xcds_used": flops_it / (us_it * 1e-6) / 1e12 / (F64_VECTOR_TFLOPS * xcds / 8),
+        }
+        r["note"] = ("row panels stay in " + residency.upper() + " for the whole launch: HBM traffic "
+                     "is the variates in and the draws out; the bound is the chain of dependent "
+                     "steps of one iteration (draw -> residual pass -> wave/group/cross-CU sums -> "
+                     "sigma2), see DESIGN.md 4.1")
+    return r
+
+
+def extras(ctx, torch, dev, local_rank, N, K, T):
+    from pybmc_amd import _lib
+    from pybmc_amd.chains import chain_seeds
+    extra = {}
+    try:
+        seeds8 = chain_seeds(1, list(range(8)))
+        out8 = torch.empty((8, T, K + 1), dtype=torch.float64, device=dev)
+        ctx.gibbs_run_device(8, T, seeds8, out8.data_ptr())
+        t1 = time.perf_counter()
+        st8 = ctx.gibbs_run_device(8, T, seeds8, out8.data_ptr())
+        torch.cuda.synchronize()
+        e8 = time.perf_counter() - t1
+        extra["chains8_one_gpu"] = {"samples_per_s": 8 * T / e8, "loop_ms": st8["loop_ms"],
+                                    "groups_per_chain": st8["groups_per_chain"]}
+        del out8
+        # 16 chains: two per XCD, still one launch
+        seeds16 = chain_seeds(1, list(range(16)))
+        out16 = torch.empty((16, T, K + 1), dtype=torch.float64, device=dev)
+        ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
+        t1 = time.perf_counter()
+        st16 = ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
+        torch.cuda.synchronize()
+        e16 = time.perf_counter() - t1
+        extra["chains16_one_gpu"] = {"samples_per_s": 16 * T / e16, "loop_ms": st16["loop_ms"],
+                                     "launches": st16["launches"]}
+        del out16
+    except Exception as e:  # never lose the headline line
+        extra["chains8_one_gpu"] = {"error": str(e)}
+    try:
+        # opt-in, reported separately (SURVEY.md 7.2-4): rss from sufficient statistics
+        # instead of the per-iteration pass over the data that the headline measures
+        ctx.set_tuning(rss_mode=1)
+        og = {}
+        for cg in (1, 256):
+            outg = torch.empty((cg, T, K + 1), dtype=torch.float64, device=dev)
+            sg = chain_seeds(1, list(range(cg)))
+            ctx.gibbs_run_device(cg, T, sg, outg.data_ptr())
+            stg = ctx.gibbs_run_device(cg, T, sg, outg.data_ptr())
+            og[f"chains{cg}"] = {"samples_per_s": cg * T / (stg["loop_ms"] * 1e-3),
+                                 "us_per_iteration": stg["loop_ms"] * 1e3 / T}
+            del outg
+        og["note"] = ("NOT the headline path: no pass over X inside the loop "
+                      "(rss(u) = rss(u0) - 2 d'g0 + d'Gd, K <= 64), one wave per chain")
+        extra["opt_in_rss_from_sufficient_statistics"] = og
+    except Exception as e:
+        extra["opt_in_rss_from_sufficient_statistics"] = {"error": str(e)}
+    finally:
+        ctx.set_tuning()
+    try:
+        # residual-reduction kernel at the C4 size (N=200000, K=64, f32 storage)
+        rng = np.random.Generator(np.random.PCG64(4))
+        X4 = np.asfortranarray(rng.standard_normal((200000, 64), dtype=np.float32))
+        y4 = rng.standard_normal(200000, dtype=np.float32)
+        c4 = _lib.Context(local_rank)
+        c4.set_problem(y4, X4, dtype=np.float32)
+        ms = c4.residual_rss_bench(nb=1, reps=50)
+        b4 = (200000 * 64 + 200000) * 4
+        extra["residual_rss_c4"] = {"ms_per_pass": ms, "achieved_GBs": b4 / (ms * 1e-3) / 1e9,
+                                    "frac_of_8TBs": b4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "bytes_per_pass": b4, "served_from": "infinity cache",
+                                    "note": "52 MB working set: served by the 256 MiB "
+                                            "Infinity Cache after the first pass"}
+        del X4, y4
+        # the same kernel on a working set that cannot stay in the Infinity Cache
+        nbig = 2_000_000
+        Xb = np.asfortranarray(rng.standard_normal((nbig, 64), dtype=np.float32))
+        yb = rng.standard_normal(nbig, dtype=np.float32)
+        c4.set_problem(yb, Xb, dtype=np.float32)
+        ms = c4.residual_rss_bench(nb=1, reps=20)
+        bb = (nbig * 64 + nbig) * 4
+        extra["residual_rss_hbm"] = {"n_obs": nbig, "k": 64, "dtype": "f32",
+                                     "ms_per_pass": ms,
+                                     "achieved_GBs": bb / (ms * 1e-3) / 1e9,
+                                     "frac_of_8TBs": bb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "bytes_per_pass": bb, "served_from": "hbm",
+                                     "note": "520 MB per pass > 256 MiB Infinity Cache: HBM-served"}
+        del Xb, yb
+        c4.close()
+    except Exception as e:
+        extra["residual_rss_c4"] = {"error": str(e)}
+    try:
+        # the persistent loop at the C4 and C5 sizes (1 chain, as on each GPU of the
+        # 8-GPU configurations); gaussian design matrices scaled to unit-norm columns
+        # ... and on a matrix larger than the 256 MiB Infinity Cache (410 MB): the streaming
+        # loop against HBM itself
+        for tag, n4, k4, dt, iters4 in (("loop_c4", 200000, 64, np.float32, 4000),
+                                        ("loop_c5", 50000, 256, np.float64, 2000),
+                                        ("loop_hbm", 400000, 256, np.float32, 500)):
+            rng = np.random.Generator(np.random.PCG64(8))
+            Xl = rng.standard_normal((n4, k4), dtype=np.float32)
+            Xl *= np.float32(1.0 / np.sqrt(n4))
+            Xl = Xl.astype(dt, copy=False)
+            yl = (Xl @ rng.standard_normal(k4).astype(dt)
+                  + 0.1 * rng.standard_normal(n4)).astype(dt)
+            cl = _lib.Context(local_rank)
+            cl.set_problem(yl, np.asfortranarray(Xl), dtype=dt)
+            cl.set_prior(np.zeros(k4), np.eye(k4) * 100.0, 1.0, 0.02)
+            outl = torch.empty((1, iters4, k4 + 1), dtype=torch.float64, device=dev)
+            cl.gibbs_run_device(1, 200, chain_seeds(1, [0]), outl.data_ptr())
+            stl = cl.gibbs_run_device(1, iters4, chain_seeds(1, [0]), outl.data_ptr())
+            bl = stl["bytes_per_pass"]
+            us = stl["loop_ms"] * 1e3 / iters4
+            # the configuration's 8 chains on this one GPU (BASELINE C4 / C5 name 8 chains)
+            it8 = max(200, iters4 // 4)
+            out8l = torch.empty((8, it8, k4 + 1), dtype=torch.float64, device=dev)
+            cl.gibbs_run_device(8, 100, chain_seeds(1, list(range(8))), out8l.data_ptr())
+            st8l = cl.gibbs_run_device(8, it8, chain_seeds(1, list(range(8))), out8l.data_ptr())
+            del out8l
+            residency = {1: "vgpr", 2: "lds", 3: "stream"}.get(stl["residency"])
+            e = {"n_obs": n4, "k": k4, "dtype": "f32" if dt == np.float32 else "f64",
+                 "chains8_us_per_iteration_all": st8l["loop_ms"] * 1e3 / it8,
+                 "chains8_samples_per_s": 8 * it8 / st8l["loop_ms"] * 1e3,
+                 "chains8_per_pass": st8l["chains_per_pass"],
+                 "us_per_iteration": us, "samples_per_s": iters4 / stl["loop_ms"] * 1e3,
+                 "algorithmic_GBs": bl / us / 1e3, "residency": residency,
+                 "bound": "hbm" if residency == "stream" and bl > 256 * 2 ** 20 else
+                          "infinity cache" if residency == "stream" else "latency",
+                 "groups": stl["groups_per_chain"], "waves": stl["waves_per_group"]}
+            if residency == "stream":   # bytes really move every iteration: an HBM-roofline fraction
+                e["frac_of_8TBs"] = bl / us / 1e3 / HBM_PEAK_GBS
+            else:                        # resident panels: bytes never move, no bandwidth fraction
+                e["algorithmic_bytes_over_time_vs_8TBs"] = bl / us / 1e3 / HBM_PEAK_GBS
+            extra[tag] = e
+            if tag == "loop_c5":
+                # the one-off f64 MFMA Gram at the C5 shape (set-up row a1)
+                ms = cl.gram_bench(reps=20)
+                fl = 2.0 * n4 * (k4 + 1) ** 2
+                extra["gram_c5"] = {"ms_per_launch_pair": ms, "flops": fl,
+                                    "TFLOPs": fl / (ms * 1e-3) / 1e12,
+                                    "frac_of_78.6TF_f64_matrix_peak": fl / (ms * 1e-3) / 1e12 / 78.6,
+                                    "bytes_read": bl, "GBs": bl / (ms * 1e-3) / 1e9,
+                                    "note": "[X y]'[X y] with v_mfma_f64_16x16x4_f64, full square "
+                                            "(symmetry not exploited), gram_mfma_kernel + gram_reduce_kernel"}
+            del outl, Xl, yl
+            cl.close()
+    except Exception as e:
+        extra["loop_c4"] = {"error": str(e)}
+    try:
+        # BASELINE configs[4]'s posterior-predictive leg at full size: 10000 draws x 50000
+        # held-out points x 257 models (reference sampling_utils.py:57-82), device generator,
+        # bands + coverage, draws left on the device (what evaluate() / predict bands need)
+        rng = np.random.Generator(np.random.PCG64(55))
+        Mp, Kmp, kp, Sp = 50000, 257, 256, 10000
+        preds = rng.standard_normal((Mp, Kmp))
+        Vt_hat = rng.standard_normal((kp, Kmp)) * 0.05
+        theta = np.column_stack([rng.standard_normal((Sp, kp)) * 0.1, rng.uniform(0.05, 0.15, Sp)])
+        truth = preds.mean(1)
+        cp = _lib.Context(local_rank)
+        for _ in range(2):
+            cp.predict(preds, theta, Vt_hat, seed=9, truth=truth,
+                       cov_percentiles=list(range(0, 101, 5)), want_draws=False)
+        tm = cp.predict_timing()
+        fl = 2.0 * Sp * Kmp * Mp
+        extra["predict_c5"] = {"points": Mp, "models": Kmp, "draws": Sp,
+                               "gemm_ms": tm["gemm_ms"], "order_stat_ms": tm["select_ms"],
+                               "device_ms": tm["device_ms"], "h2d_ms": tm["h2d_ms"],
+                               "gemm_TFLOPs": fl / (tm["gemm_ms"] * 1e-3) / 1e12,
+                               "gemm_frac_of_78.6TF_f64_matrix_peak":
+                                   fl / (tm["gemm_ms"] * 1e-3) / 1e12 / 78.6,
+                               "draws_written_GB": Mp * Sp * 8 / 1e9,
+                               "reference_cpu_s_at_M5000_K32": 11.7}
+        cp.close()
+    except Exception as e:
+        extra["predict_c5"] = {"error": str(e)}
+    return extra
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args, argv))
+    rank_main(args)
 
 
 if __name__ == "__main__":

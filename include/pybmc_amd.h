@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PYBMC_AMD_ABI_VERSION 2
+#define PYBMC_AMD_ABI_VERSION 3
 
 typedef struct bmc_ctx bmc_ctx;
 
@@ -58,6 +58,12 @@ typedef struct {
                                  rss(u) = rss(u0) - 2 d'g0 + d'G d with d = u - u0, G = X~'X~,
                                  g0 = X~'(y - X~ u0) and u0 the least-squares point; no pass
                                  over the data inside the loop, one wave per chain          */
+    int32_t cu_limit;         /* 0: the device's CU count.  > 0: plan as if only this many CUs could
+                                 hold workgroups of a persistent launch (a CU-masked queue, a
+                                 partition, a GPU shared with another process).  The persistent
+                                 kernels need all groups of a launch resident at once; geometry and
+                                 the residency check (BMC_EINVAL instead of a spin that times out)
+                                 follow this number                                           */
 } bmc_tuning;
 
 /* Filled by bmc_gibbs_run*.  Times are HIP-event times on the context's stream. */
@@ -141,6 +147,10 @@ int bmc_residual_rss(bmc_ctx* ctx, const double* beta, int32_t nb, double* rss_o
 /* Same kernel launched `reps` times back to back on data already in HBM; returns
  * the HIP-event time per launch.  Roofline measurement only. */
 int bmc_residual_rss_bench(bmc_ctx* ctx, int32_t nb, int32_t reps, double* ms_per_launch);
+/* The augmented Gram [X y]'[X y] of the resident problem (f64 MFMA kernel + its reduction,
+ * inference_utils.py:25 and the X'y of :43) launched `reps` times back to back; HIP-event time
+ * per launch pair.  Roofline measurement only. */
+int bmc_gram_bench(bmc_ctx* ctx, int32_t reps, double* ms_per_launch);
 
 /* ---- the Gibbs loop ---------------------------------------------------------
  * Replaces the loop of gibbs_sampler, pybmc/inference_utils.py:39-56, for
@@ -199,6 +209,30 @@ int bmc_predict(bmc_ctx* ctx, const double* preds, int64_t n_points, int32_t n_m
                 const int32_t* q_index, const double* q_gamma, int32_t n_q,
                 const double* truth, const int32_t* cov_lo, const int32_t* cov_hi,
                 int32_t n_cov, double* rndm_m_out, double* bands_out, int64_t* cov_hits_out);
+
+/* HIP-event times of the LAST bmc_predict on this context (any pointer may be NULL):
+ * h2d_ms the host->device copies of its inputs, gemm_ms the weight + MFMA GEMM(+noise)
+ * kernels, orderstat_ms the selection / sort kernels, device_ms first copy -> last kernel. */
+int bmc_predict_timing(bmc_ctx* ctx, double* h2d_ms, double* gemm_ms, double* orderstat_ms,
+                       double* device_ms);
+
+/* ---- pooling the chains of several GPUs (a capability the reference lacks) ----
+ * One process per GPU; rank r samples its block of chains with no communication, then ONE
+ * all-gather over RCCL (xGMI) pools the per-rank blocks.  RCCL (librccl.so.1) is loaded on
+ * first use, so a single-GPU caller needs no RCCL at all.
+ *   bmc_comm_unique_id   rank 0 creates the 128-byte RCCL id; the caller hands it to the other
+ *                        ranks by whatever transport it has (file, socket, MPI, env)
+ *   bmc_comm_init        collective over all ranks; binds the communicator to ctx's device
+ *   bmc_allgather        d_recv[r * count .. (r+1) * count) = rank r's d_send[0 .. count), f64;
+ *                        DEVICE pointers; d_send may alias its own slot of d_recv (in place).
+ *                        Runs on the context's stream, after every sampler launch queued there,
+ *                        and returns when the pooled block is complete.
+ *   bmc_comm_destroy     also done by bmc_destroy */
+#define BMC_COMM_ID_BYTES 128
+int bmc_comm_unique_id(char id_out[BMC_COMM_ID_BYTES]);
+int bmc_comm_init(bmc_ctx* ctx, int32_t world, int32_t rank, const char id[BMC_COMM_ID_BYTES]);
+int bmc_allgather(bmc_ctx* ctx, const void* d_send, void* d_recv, int64_t count_per_rank);
+int bmc_comm_destroy(bmc_ctx* ctx);
 
 /* ---- on-device variates (exposed so the generator itself can be tested) ----
  * normals_out [count_normal] ~ N(0,1); gammas_out [count_gamma] ~ Gamma(shape,1). */

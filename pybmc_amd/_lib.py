@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpybmc_amd.so")
 
-ABI_VERSION = 2   # PYBMC_AMD_ABI_VERSION of include/pybmc_amd.h this binding was written for
+ABI_VERSION = 3   # PYBMC_AMD_ABI_VERSION of include/pybmc_amd.h this binding was written for
 BMC_OK, BMC_EINVAL, BMC_ESINGULAR, BMC_EHIP, BMC_ENOMEM, BMC_ETIMEOUT, BMC_ESTATE = range(7)
 BMC_F64, BMC_F32 = 0, 1
 BMC_ROW_MAJOR, BMC_COL_MAJOR = 0, 1
@@ -27,7 +27,7 @@ class Tuning(C.Structure):
     _fields_ = [("groups_per_chain", C.c_int32), ("waves_per_group", C.c_int32),
                 ("residency", C.c_int32), ("panels_per_wave", C.c_int32),
                 ("force_agent_scope", C.c_int32), ("chains_per_pass", C.c_int32),
-                ("rss_mode", C.c_int32)]
+                ("rss_mode", C.c_int32), ("cu_limit", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -64,6 +64,12 @@ PROTOTYPES = {
     "bmc_conditional_moments": (C.c_int, [_P, C.c_double, _D, _D]),
     "bmc_residual_rss": (C.c_int, [_P, _D, C.c_int32, _D]),
     "bmc_residual_rss_bench": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
+    "bmc_gram_bench": (C.c_int, [_P, C.c_int32, _D]),
+    "bmc_predict_timing": (C.c_int, [_P, _D, _D, _D, _D]),
+    "bmc_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "bmc_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_char_p]),
+    "bmc_allgather": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "bmc_comm_destroy": (C.c_int, [_P]),
     "bmc_gibbs_run": (C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_uint64), C.c_int, _D, _D,
                                 _D, C.POINTER(Stats)]),
     "bmc_gibbs_run_device": (C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(C.c_uint64), _P,
@@ -152,6 +158,10 @@ class Context:
         self._h = h
         self.device = int(device)
         self.n = self.k = 0
+        # bumped whenever the resident (y, X) changes: lets a caller that left a problem on the
+        # device (BayesianModelCombination.orthogonalize(method="device")) find out whether it
+        # is still there before sampling from it
+        self.problem_generation = 0
 
     # -- plumbing --------------------------------------------------------------
     def close(self):
@@ -181,12 +191,13 @@ class Context:
         self._check(self._lib.bmc_set_stream(self._h, _P(hip_stream_ptr or 0)))
 
     def set_tuning(self, groups_per_chain=0, waves_per_group=0, residency=0, panels_per_wave=0,
-                   force_agent_scope=0, chains_per_pass=0, rss_mode=0):
+                   force_agent_scope=0, chains_per_pass=0, rss_mode=0, cu_limit=0):
         """residency: 0 auto, 1 registers, 2 LDS, 3 stream from HBM; chains_per_pass: 0 auto,
         1 off, 2/4/8 cap; rss_mode: 0 a pass over the data every iteration (the reference's
-        computation, default), 1 the same number from sufficient statistics (opt-in, K <= 64)."""
+        computation, default), 1 the same number from sufficient statistics (opt-in, K <= 64);
+        cu_limit: plan persistent launches for at most this many CUs (0 = the device's)."""
         t = Tuning(groups_per_chain, waves_per_group, residency, panels_per_wave,
-                   force_agent_scope, chains_per_pass, rss_mode)
+                   force_agent_scope, chains_per_pass, rss_mode, cu_limit)
         self._check(self._lib.bmc_set_tuning(self._h, C.byref(t)))
 
     # -- problem / prior ---------------------------------------------------------
@@ -209,12 +220,14 @@ class Context:
             layout, ldx = BMC_ROW_MAJOR, X.shape[1]
         yc = np.ascontiguousarray(y, dtype=dtype)
         n, k = X.shape
+        self.problem_generation += 1   # (before the call: a failed call leaves no problem)
         self._check(self._lib.bmc_set_problem(
             self._h, Xc.ctypes.data_as(_P), n, k, max(ldx, 1), layout, yc.ctypes.data_as(_P),
             BMC_F32 if dtype == np.float32 else BMC_F64))
         self.n, self.k = n, k
 
     def set_problem_device(self, x_ptr, n, k, ldx, layout, y_ptr, f32=False):
+        self.problem_generation += 1
         self._check(self._lib.bmc_set_problem_device(
             self._h, _P(x_ptr), n, k, ldx, layout, _P(y_ptr), BMC_F32 if f32 else BMC_F64))
         self.n, self.k = n, k
@@ -230,6 +243,7 @@ class Context:
         mu, yc = np.empty(n), np.empty(n)
         U = np.empty((k, n)) if want_U else None
         S, Vt = np.empty(k), np.empty((k, km))
+        self.problem_generation += 1
         self._check(self._lib.bmc_orthogonalize(self._h, _dptr(F), n, km, km, _dptr(truth), int(k),
                                                 _dptr(mu), _dptr(yc), _dptr(U), _dptr(S), _dptr(Vt)))
         self.n, self.k = n, int(k)
@@ -275,6 +289,40 @@ class Context:
         ms = C.c_double()
         self._check(self._lib.bmc_residual_rss_bench(self._h, nb, reps, C.byref(ms)))
         return ms.value
+
+    def gram_bench(self, reps=20):
+        ms = C.c_double()
+        self._check(self._lib.bmc_gram_bench(self._h, reps, C.byref(ms)))
+        return ms.value
+
+    def predict_timing(self):
+        """HIP-event times (ms) of the last predict() on this context."""
+        v = [C.c_double() for _ in range(4)]
+        self._check(self._lib.bmc_predict_timing(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("h2d_ms", "gemm_ms", "select_ms", "device_ms"), (x.value for x in v)))
+
+    # -- pooling over GPUs without torch (RCCL through the C ABI) ------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id made by rank 0; hand it to the other ranks by any transport."""
+        buf = C.create_string_buffer(128)
+        rc = load_library().bmc_comm_unique_id(buf)
+        if rc != BMC_OK:
+            raise BmcError(f"bmc_comm_unique_id failed with status {rc}: RCCL could not be loaded")
+        return buf.raw
+
+    def comm_init(self, world, rank, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._check(self._lib.bmc_comm_init(self._h, int(world), int(rank), bytes(unique_id)))
+
+    def allgather(self, send_ptr, recv_ptr, count_per_rank):
+        """f64 all-gather of DEVICE buffers on the context's stream; blocks until done."""
+        self._check(self._lib.bmc_allgather(self._h, _P(send_ptr), _P(recv_ptr),
+                                            int(count_per_rank)))
+
+    def comm_destroy(self):
+        self._check(self._lib.bmc_comm_destroy(self._h))
 
     # -- the loop --------------------------------------------------------------------
     def gibbs_run(self, n_chains, iters, seeds=None, xi=None, g=None):

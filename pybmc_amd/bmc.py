@@ -80,7 +80,10 @@ class BayesianModelCombination:
                 raise ValueError(str(e)) from None
             U_hat = np.asfortranarray(U_hat)
             Vt_hat = Vt_norm / S_hat[:, None]
-            self._device_problem = (ctx, U_hat, y_c)   # the context already holds (y_c, U_hat)
+            # the context already holds (y_c, U_hat) -- for as long as nobody else (another
+            # BayesianModelCombination, a functional gibbs_sampler call: the per-device context
+            # is shared) puts a different problem there: remember its generation
+            self._device_problem = (ctx, U_hat, y_c, ctx.problem_generation)
         else:
             mu = np.mean(F, axis=1)
             y_c = train_df[self.truth_column_name].values - mu
@@ -100,7 +103,11 @@ class BayesianModelCombination:
     def train(self, training_options=None):
         """Sample the posterior (reference bmc.py:132-193).  Options and their defaults
         are the reference's; any sampler string other than ``"simplex"`` selects the
-        Gibbs sampler (quirk Q6).  Extra optional keys: ``n_chains``, ``seeds``."""
+        Gibbs sampler (quirk Q6).  Extra optional keys (defaults keep the reference behaviour):
+        ``n_chains`` (pooled along the sample axis), ``seeds``, ``dtype`` (``"float32"`` stores
+        U_hat and y in float32 on the device, sums stay float64 -- BASELINE configs[3]),
+        ``devices`` (list of GPU ids: the chains are split over them, one host thread and one
+        context per device, and pooled in chain order)."""
         if self.U_hat is None:
             raise ValueError("Must call `orthogonalize()` before training.")
         opts = training_options if training_options is not None else {}
@@ -126,14 +133,29 @@ class BayesianModelCombination:
                 self.centered_experiment_train, self.U_hat, self.Vt_hat, self.S_hat,
                 iterations, [nu0, sigma20], burn=burn, stepsize=stepsize, device=self.device)
         else:
-            dp = self._device_problem
-            on_device = (dp is not None and dp[1] is self.U_hat
-                         and dp[2] is self.centered_experiment_train)
-            res, stats = gibbs_sampler(
-                self.centered_experiment_train, self.U_hat, iterations,
-                [b_mean_prior, b_mean_cov, nu0, sigma20],
-                n_chains=int(opts.get("n_chains", 1)), seeds=opts.get("seeds"),
-                device=self.device, return_stats=True, _problem_on_device=on_device)
+            dtype = opts.get("dtype")
+            if dtype is not None and np.dtype(dtype) not in (np.dtype(np.float32),
+                                                             np.dtype(np.float64)):
+                raise ValueError("dtype must be float32 or float64")
+            devices = opts.get("devices")
+            n_chains = int(opts.get("n_chains", 1))
+            prior = [b_mean_prior, b_mean_cov, nu0, sigma20]
+            if devices is not None and list(devices) != [self.device]:
+                from .chains import run_on_devices
+                res, stats = run_on_devices(self.centered_experiment_train, self.U_hat, iterations,
+                                            prior, n_chains, opts.get("seeds"), list(devices), dtype)
+            else:
+                dp = self._device_problem
+                # the resident problem is reusable only if it is still THIS object's: same
+                # arrays, same context generation, and float64 storage was asked for
+                on_device = (dp is not None and dp[1] is self.U_hat
+                             and dp[2] is self.centered_experiment_train
+                             and dp[0].problem_generation == dp[3]
+                             and (dtype is None or np.dtype(dtype) == np.float64))
+                res, stats = gibbs_sampler(
+                    self.centered_experiment_train, self.U_hat, iterations, prior,
+                    n_chains=n_chains, seeds=opts.get("seeds"), dtype=dtype,
+                    device=self.device, return_stats=True, _problem_on_device=on_device)
             self.last_stats = stats
             # several chains are pooled along the sample axis
             self.samples = res if res.ndim == 2 else res.reshape(-1, res.shape[-1])

@@ -60,6 +60,13 @@ def pool_samples(local_block, n_chains, group=None):
     pooled = torch.empty((world * mb, T, k1), dtype=local_block.dtype,
                          device=local_block.device)
     dist.all_gather_into_tensor(pooled, send.contiguous(), group=group)
+    if local_block.is_cuda:
+        # RCCL runs the collective on its own stream and torch only makes ITS current stream
+        # wait for it.  The sampler writes `local_block` on the library's own non-blocking
+        # stream, which is ordered against neither: wait here, on the host, until the
+        # collective has read `send` (= `local_block` itself when the blocks are even), so the
+        # caller may hand the same buffer to the next run.
+        torch.cuda.current_stream(local_block.device).synchronize()
     if n_chains == world * mb:
         return pooled
     keep = []
@@ -92,11 +99,62 @@ def run_chains(ctx, n_chains, iterations, base_seed=0, group=None, out=None):
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     mine = chain_block(n_chains, world, rank)
-    dev = torch.device("cuda", ctx.device)
+    # (a context may name the torch device its buffers live on; a bmc_ctx is always a GPU)
+    dev = getattr(ctx, "torch_device", None) or torch.device("cuda", ctx.device)
     if out is None:
         out = torch.empty((len(mine), iterations, ctx.k + 1), dtype=torch.float64, device=dev)
+    elif tuple(out.shape) != (len(mine), iterations, ctx.k + 1) or out.dtype != torch.float64 \
+            or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float64 [chains of this rank, iterations, k+1]")
     stats = None
     if mine:
         stats = ctx.gibbs_run_device(len(mine), iterations, chain_seeds(base_seed, mine),
                                      out.data_ptr())
     return pool_samples(out, n_chains, group), stats
+
+
+def run_on_devices(y, X, iterations, prior_info, n_chains, seeds, devices, dtype=None):
+    """Several GPUs driven from ONE process (what ``train(devices=[...])`` uses): the chains
+    are split over the devices like ranks split them (``chain_block``), each device gets its own
+    context and host thread (the C ABI releases the GIL and a bmc_ctx is single-threaded), and
+    the blocks are concatenated in global chain order.  A device listed twice is used once: two
+    persistent launches on one GPU would compete for the same CUs.
+    Returns (samples [iterations, k+1] or [n_chains, iterations, k+1], list of per-device stats)."""
+    import threading
+
+    from . import _lib
+    from .inference_utils import _draw_seeds
+
+    devs = list(dict.fromkeys(int(d) for d in devices))
+    if not devs:
+        raise ValueError("devices must name at least one GPU")
+    if seeds is None:
+        seeds = _draw_seeds(n_chains)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(n_chains)
+    blocks = [chain_block(n_chains, len(devs), i) for i in range(len(devs))]
+    results, errors = [None] * len(devs), [None] * len(devs)
+    b0, C0, nu0, s20 = prior_info
+    ctxs = [_lib.default_context(d) for d in devs]   # (created here: the cache is not thread-safe)
+
+    def work(i):
+        try:
+            if not blocks[i]:
+                return
+            ctx = ctxs[i]
+            ctx.set_problem(y, X, dtype=dtype)
+            ctx.set_prior(b0, C0, nu0, s20)
+            results[i] = ctx.gibbs_run(len(blocks[i]), int(iterations), seeds=seeds[blocks[i]])
+        except BaseException as e:     # re-raised on the calling thread
+            errors[i] = e
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(devs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    out = np.concatenate([r[0] for r in results if r is not None], axis=0)
+    stats = [r[1] for r in results if r is not None]
+    return (out[0] if n_chains == 1 else out), stats

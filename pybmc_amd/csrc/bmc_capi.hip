@@ -1,6 +1,8 @@
 // C ABI of libpybmc_amd.so (see include/pybmc_amd.h).  Host orchestration only:
 // every O(N) step is a gfx950 kernel; the host does the one-off K x K algebra.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library itself is loaded on first use (bmc_comm_*)
 
 #include <algorithm>
 #include <cmath>
@@ -33,7 +35,7 @@ struct bmc_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    bmc_tuning tune{0, 0, 0, 0, 0, 0, 0};
+    bmc_tuning tune{};
     int n_cu = 256;
 
     // problem
@@ -63,6 +65,10 @@ struct bmc_ctx {
     DevBuf sVt, sStep, sUnif, sOut, sCnt;
     DevBuf oFc, oMu, oW, oOut;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double predict_ms[4] = {0, 0, 0, 0};   // last bmc_predict: h2d, gemm, order statistics, device
+    // pooling over GPUs (bmc_comm_*): RCCL communicator bound to this context's device
+    ncclComm_t comm = nullptr;
+    int32_t comm_world = 0, comm_rank = 0;
 };
 
 namespace {
@@ -229,6 +235,9 @@ struct Chip {
 Chip chip_of(const bmc_ctx* c) {
     Chip ch;
     ch.groups_max = c->n_cu > 0 ? c->n_cu : 256;
+    // bmc_tuning.cu_limit: fewer CUs can hold this context's persistent workgroups than the
+    // device reports (CU-masked queue, a GPU shared with another process)
+    if (c->tune.cu_limit > 0 && c->tune.cu_limit < ch.groups_max) ch.groups_max = c->tune.cu_limit;
     if (ch.groups_max > 256) ch.groups_max = 256;   // the gather holds 2 x 256 granules
     ch.xcds = ch.groups_max >= 64 ? ch.groups_max / 32 : 1;
     ch.cu_per_xcd = ch.groups_max / ch.xcds;
@@ -387,6 +396,41 @@ int gram_device_setup(bmc_ctx* c) {
     return BMC_OK;
 }
 
+// The workgroups of a persistent launch wait for each other inside the kernel, so all of them
+// must be resident at once.  A plain launch checks nothing (an over-subscribed grid would spin
+// until the bounded spins expire, 4 s): ask the runtime how many workgroups of exactly this
+// kernel, block size and LDS footprint one CU admits and compare with what the launch keeps
+// resident.  `resident` = workgroups that stay in the loop (unused slots leave at once).
+template <typename Args, typename Launch>
+int check_residency(bmc_ctx* c, Args a, int resident, Launch launch, const char* what) {
+    int32_t per_cu = 0;
+    a.query_occupancy = &per_cu;
+    const hipError_t e = launch(a, c->stream);
+    if (e != hipSuccess)
+        return fail(c, e == hipErrorInvalidValue ? BMC_EINVAL : BMC_EHIP,
+                    std::string(what) + ": no kernel for this geometry (" + hipGetErrorString(e) + ")");
+    const long cap = (long)per_cu * chip_of(c).groups_max;
+    if ((long)resident > cap)
+        return fail(c, BMC_EINVAL,
+                    std::string(what) + ": the launch needs " + std::to_string(resident) +
+                        " co-resident workgroups but the device admits " + std::to_string(cap) + " (" +
+                        std::to_string(per_cu) + " per CU x " + std::to_string(chip_of(c).groups_max) +
+                        " CUs); use fewer groups_per_chain / waves_per_group or another residency");
+    return BMC_OK;
+}
+
+// an explicit geometry request that the (possibly limited) chip cannot hold is an error, not
+// something to clamp silently
+int check_tuning_fits(bmc_ctx* c) {
+    const Chip chip = chip_of(c);
+    if (c->tune.groups_per_chain > chip.groups_max)
+        return fail(c, BMC_EINVAL,
+                    "groups_per_chain = " + std::to_string(c->tune.groups_per_chain) + " exceeds the " +
+                        std::to_string(chip.groups_max) +
+                        " workgroups that can be resident at once (one per CU; bmc_tuning.cu_limit)");
+    return BMC_OK;
+}
+
 int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seeds, int rng_mode,
                const double* xi, const double* g, double* samples_host, void* samples_dev,
                bmc_stats* stats) {
@@ -414,6 +458,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         if ((rc = ensure(c, c->samples, C * T * (K + 1) * 8))) return rc;
         d_samples = (double*)c->samples.p;
     }
+    if ((rc = check_tuning_fits(c))) return rc;
     Geometry geo = choose_geometry(c, n_chains);
     // One-XCD register residency with more than 8 chains: chains c and c + 8 share XCD c % 8,
     // two workgroups per CU side by side.  That needs 4 waves per SIMD (two 5-wave groups must
@@ -429,7 +474,13 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         q.G = geo.G; q.waves = geo.waves; q.mode = geo.mode; q.reg_ppw = geo.ppw;
         q.nslot = geo.nslot; q.n_chains = 1; q.chains_per_pass = 1; q.panels_per_group = geo.ppg;
         q.query_regs = &regs;
-        if (launch_gibbs(q, c->stream) == hipSuccess && regs > 0 && regs <= 128) {
+        int32_t per_cu = 0;
+        GibbsArgs qo = q;
+        qo.query_regs = nullptr;
+        qo.pack = 1;
+        qo.query_occupancy = &per_cu;
+        if (launch_gibbs(q, c->stream) == hipSuccess && regs > 0 && regs <= 128 &&
+            launch_gibbs(qo, c->stream) == hipSuccess && per_cu >= 2) {
             pack = 1;
             geo.nslot *= 2;
             geo.chains_per_launch = n_chains < geo.nslot ? n_chains : geo.nslot;
@@ -549,6 +600,10 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         a.placement = (int32_t*)c->placement.p + c0;
         HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)m * 3 * gran_stride * 8, c->stream));
         if (gibbs_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
+        if (a.G > 1 || cpp > 1)   // (a single-workgroup chain waits for nobody)
+            if ((rc = check_residency(c, a, (cpp > 1 ? 1 : m) * a.G, launch_gibbs,
+                                      "persistent Gibbs kernel")))
+                return rc;
         HIPCHK(c, launch_gibbs(a, c->stream));
         ++launches;
         c0 += m;
@@ -631,6 +686,7 @@ int bmc_create(int device_id, bmc_ctx** out) {
 
 void bmc_destroy(bmc_ctx* c) {
     if (!c) return;
+    (void)bmc_comm_destroy(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->Xraw, &c->Yp, &c->Xrot, &c->dW, &c->dWT, &c->dLam, &c->dC1, &c->dC2,
@@ -666,7 +722,7 @@ int bmc_set_stream(bmc_ctx* c, void* hip_stream) {
 int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
     if (!c) return BMC_EINVAL;
     if (!t) {
-        c->tune = bmc_tuning{0, 0, 0, 0, 0, 0, 0};
+        c->tune = bmc_tuning{};
         return BMC_OK;
     }
     if (t->groups_per_chain < 0 || t->groups_per_chain > 256 || t->waves_per_group < 0 ||
@@ -675,9 +731,10 @@ int bmc_set_tuning(bmc_ctx* c, const bmc_tuning* t) {
          t->panels_per_wave != 4) ||
         (t->chains_per_pass != 0 && t->chains_per_pass != 1 && t->chains_per_pass != 2 &&
          t->chains_per_pass != 4 && t->chains_per_pass != 8) ||
-        (t->rss_mode != 0 && t->rss_mode != 1))
+        (t->rss_mode != 0 && t->rss_mode != 1) || t->cu_limit < 0)
         return fail(c, BMC_EINVAL, "tuning out of range (groups 0..256, waves 0..8, residency 0..3, "
-                                   "panels_per_wave 0/1/2/4, chains_per_pass 0/1/2/4/8, rss_mode 0/1)");
+                                   "panels_per_wave 0/1/2/4, chains_per_pass 0/1/2/4/8, rss_mode 0/1, "
+                                   "cu_limit >= 0)");
     c->tune = *t;
     return BMC_OK;
 }
@@ -1024,6 +1081,28 @@ int bmc_residual_rss_bench(bmc_ctx* c, int32_t nb, int32_t reps, double* ms_per_
     return BMC_OK;
 }
 
+int bmc_gram_bench(bmc_ctx* c, int32_t reps, double* ms_per_launch) {
+    if (!c) return BMC_EINVAL;
+    if (!c->have_problem) return fail(c, BMC_ESTATE, "no problem set");
+    if (reps < 1 || !ms_per_launch) return fail(c, BMC_EINVAL, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const Panels P = panels_of(c, c->Xraw.p);
+    int rc;
+    if ((rc = ensure(c, c->gramScratch, gram_scratch_bytes(P)))) return rc;
+    if ((rc = ensure(c, c->gramOut, (size_t)(c->k + 1) * (c->k + 1) * 8))) return rc;
+    for (int i = 0; i < 2; ++i)
+        HIPCHK(c, launch_gram(P, c->gramScratch.p, (double*)c->gramOut.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    for (int i = 0; i < reps; ++i)
+        HIPCHK(c, launch_gram(P, c->gramScratch.p, (double*)c->gramOut.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    *ms_per_launch = (double)ms / reps;
+    return BMC_OK;
+}
+
 int bmc_gibbs_run(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seeds, int rng_mode,
                   const double* xi, const double* g, double* samples_out, bmc_stats* stats) {
     if (!c) return BMC_EINVAL;
@@ -1103,6 +1182,7 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     if ((rc = ensure(c, c->sUnif, (size_t)(n_unif > 0 ? n_unif : 1) * 8))) return rc;
     std::vector<double> step(K);
     for (int j = 0; j < K; ++j) step[j] = std::sqrt(S_hat[j] * S_hat[j] * stepsize * stepsize);  // :80
+    if ((rc = check_tuning_fits(c))) return rc;
     const Geometry geo = choose_geometry(c, 1);
     const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)3 * gran_stride * 8))) return rc;
@@ -1159,7 +1239,12 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     a.panels_per_group = geo.ppg;
     if (a.vt_in_lds && simplex_lds_bytes(a) > LDS_LIMIT) a.vt_in_lds = 0;
     if (simplex_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
-    if (Tt > 0) HIPCHK(c, launch_simplex(a, c->stream));
+    if (Tt > 0) {
+        if (a.G > 1 &&
+            (rc = check_residency(c, a, a.G, launch_simplex, "persistent simplex kernel")))
+            return rc;
+        HIPCHK(c, launch_simplex(a, c->stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     int32_t st = 0, place = 0;
     long long cnt[2] = {0, 0};
@@ -1239,6 +1324,7 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
     const size_t offT = offFC + 16, offFP = offT + (size_t)M * 8;
     if ((rc = ensure(c, c->pAux, offFP + (size_t)M * 4))) return rc;
     char* aux = (char*)c->pAux.p;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(aux, 0, offT, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->pPreds.p, preds, szP, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->pTheta.p, theta, szT, hipMemcpyHostToDevice, c->stream));
@@ -1273,7 +1359,10 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
     a.hits = (unsigned long long*)(aux + offH);
     a.fail_count = (int32_t*)(aux + offFC);
     a.fail_points = (int32_t*)(aux + offFP);
+    a.ev_mid = c->ev[2];
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, launch_predict(a, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     if (n_q)
         HIPCHK(c, hipMemcpyAsync(bands_out, c->pBands.p, (size_t)n_q * M * 8, hipMemcpyDeviceToHost,
                                  c->stream));
@@ -1283,6 +1372,118 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
     if (rndm_m_out)
         HIPCHK(c, hipMemcpy2DAsync(rndm_m_out, (size_t)S * 8, c->pR.p, (size_t)a.S_pad * 8,
                                    (size_t)S * 8, (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->predict_ms[0] = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->predict_ms[1] = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->predict_ms[2] = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); c->predict_ms[3] = ms;
+    }
+    return BMC_OK;
+}
+
+int bmc_predict_timing(bmc_ctx* c, double* h2d_ms, double* gemm_ms, double* orderstat_ms,
+                       double* device_ms) {
+    if (!c) return BMC_EINVAL;
+    if (h2d_ms) *h2d_ms = c->predict_ms[0];
+    if (gemm_ms) *gemm_ms = c->predict_ms[1];
+    if (orderstat_ms) *orderstat_ms = c->predict_ms[2];
+    if (device_ms) *device_ms = c->predict_ms[3];
+    return BMC_OK;
+}
+
+// ---- pooling over GPUs: RCCL, loaded on first use --------------------------------------
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+// One RCCL per process: the copy already in the process (torch loads its own, same soname)
+// wins; otherwise the loader's search path, then the ROCm install.
+const Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.h ? &r : nullptr;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+        if (!r.h) r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if (!r.h) r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.h) return nullptr;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
+        r.h = nullptr;
+    return r.h ? &r : nullptr;
+}
+#define RCCLCHK(ctx, R, expr)                                                          \
+    do {                                                                               \
+        ncclResult_t r__ = (expr);                                                     \
+        if (r__ != ncclSuccess)                                                        \
+            return fail(ctx, BMC_EHIP, std::string(#expr) + ": " + (R)->GetErrorString(r__)); \
+    } while (0)
+}  // namespace
+
+int bmc_comm_unique_id(char id_out[BMC_COMM_ID_BYTES]) {
+    static_assert(BMC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id_out) return BMC_EINVAL;
+    const Rccl* R = rccl();
+    if (!R) return BMC_EHIP;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return BMC_EHIP;
+    std::memcpy(id_out, id.internal, BMC_COMM_ID_BYTES);
+    return BMC_OK;
+}
+
+int bmc_comm_destroy(bmc_ctx* c) {
+    if (!c) return BMC_EINVAL;
+    if (c->comm) {
+        const Rccl* R = rccl();
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (R) (void)R->CommDestroy(c->comm);
+        c->comm = nullptr;
+        c->comm_world = c->comm_rank = 0;
+    }
+    return BMC_OK;
+}
+
+int bmc_comm_init(bmc_ctx* c, int32_t world, int32_t rank, const char id[BMC_COMM_ID_BYTES]) {
+    if (!c) return BMC_EINVAL;
+    if (!id || world < 1 || rank < 0 || rank >= world)
+        return fail(c, BMC_EINVAL, "need world >= 1, 0 <= rank < world and an id");
+    const Rccl* R = rccl();
+    if (!R) return fail(c, BMC_EHIP, std::string("librccl.so.1 could not be loaded: ") +
+                                         (dlerror() ? dlerror() : "symbols missing"));
+    HIPCHK(c, hipSetDevice(c->device));
+    bmc_comm_destroy(c);
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, BMC_COMM_ID_BYTES);
+    RCCLCHK(c, R, R->CommInitRank(&c->comm, world, uid, rank));
+    c->comm_world = world;
+    c->comm_rank = rank;
+    return BMC_OK;
+}
+
+int bmc_allgather(bmc_ctx* c, const void* d_send, void* d_recv, int64_t count_per_rank) {
+    if (!c) return BMC_EINVAL;
+    if (!c->comm) return fail(c, BMC_ESTATE, "bmc_comm_init must be called first");
+    if (!d_send || !d_recv || count_per_rank < 0) return fail(c, BMC_EINVAL, "bad arguments");
+    const Rccl* R = rccl();
+    if (!R) return fail(c, BMC_EHIP, "RCCL is not loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (count_per_rank > 0)
+        RCCLCHK(c, R, R->AllGather(d_send, d_recv, (size_t)count_per_rank, ncclFloat64, c->comm,
+                                   c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return BMC_OK;
 }

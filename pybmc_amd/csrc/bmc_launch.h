@@ -97,6 +97,7 @@ struct PredictArgs {
     unsigned long long* hits;  // [n_cov], zeroed
     int32_t* fail_points;  // [M] points the selection kernel hands to the sort kernel (or NULL)
     int32_t* fail_count;   // [1], zeroed
+    hipEvent_t ev_mid = nullptr;  // recorded between the GEMM and the order statistics (or NULL)
 };
 hipError_t launch_predict(const PredictArgs& a, hipStream_t s);
 
@@ -130,6 +131,10 @@ struct GibbsArgs {
                             // VGPR count of the packed (<= 128 VGPR) variant of the kernel it
                             // would have launched, 0 if that shape has none
     int32_t pack;           // 1: launch the packed variant (two chains per XCD)
+    int32_t* query_occupancy = nullptr;  // host pointer; when set launch_gibbs launches nothing and
+                            // reports how many workgroups of the kernel / block size / LDS bytes it
+                            // would have launched ONE CU admits (hipOccupancyMaxActiveBlocksPer
+                            // Multiprocessor): the persistent kernels need every group resident
 };
 // rss from sufficient statistics (bmc_tuning.rss_mode = 1): one wave per chain, K <= 64
 struct GramArgs {
@@ -170,6 +175,7 @@ struct SimplexArgs {
     long long* counters;    // [2] accepted (sampling phase), uniforms consumed
     int64_t iters, burn;
     int32_t G, waves, mode, reg_ppw, nslot, force_agent_scope, panels_per_group;
+    int32_t* query_occupancy = nullptr;  // as in GibbsArgs
 };
 size_t simplex_lds_bytes(const SimplexArgs& a);
 hipError_t launch_simplex(const SimplexArgs& a, hipStream_t s);

@@ -660,6 +660,26 @@ size_t simplex_lds_bytes(const SimplexArgs& a) {
 struct GibbsTag {};
 struct SimplexTag {};
 
+// Launch `fn` -- or, when `occ` is set, launch nothing and report how many workgroups of this
+// block size and LDS footprint one CU admits (the persistent kernels spin on each other, so the
+// host checks residency before it launches: bmc_capi.hip, check_residency).
+template <typename Args>
+static hipError_t launch_or_query(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                                  const Args& a, int32_t* occ) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (occ) {
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)block.x, lds);
+        *occ = nb;
+        return e;
+    }
+    Args copy = a;
+    void* params[] = {&copy};
+    e = hipLaunchKernel(fn, grid, block, params, lds, s);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
@@ -674,44 +694,25 @@ static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
         }
         return hipSuccess;
     }
+    const dim3 grid(a.nslot * a.G), block(64 * a.waves);
     if constexpr (loop_can_pack<T, VEC, MODE, KMAX, PPW>()) {
-        if (a.pack && a.G > 1) {
-            hipError_t e = hipFuncSetAttribute(
-                (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>,
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>),
-                               dim3(a.nslot * a.G), dim3(64 * a.waves), lds, s, a);
-            return hipGetLastError();
-        }
+        if (a.pack && a.G > 1)
+            return launch_or_query((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>,
+                                   grid, block, lds, s, a, a.query_occupancy);
     }
     if constexpr (MODE == MODE_REG) {
-        if (a.G == 1) {  // the chain fits one workgroup: no exchange code at all
-            hipError_t e = hipFuncSetAttribute(
-                (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>,
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>),
-                               dim3(a.nslot * a.G), dim3(64 * a.waves), lds, s, a);
-            return hipGetLastError();
-        }
+        if (a.G == 1)   // the chain fits one workgroup: no exchange code at all
+            return launch_or_query((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>,
+                                   grid, block, lds, s, a, a.query_occupancy);
     }
-    hipError_t e = hipFuncSetAttribute((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>), dim3(a.nslot * a.G),
-                       dim3(64 * a.waves), lds, s, a);
-    return hipGetLastError();
+    return launch_or_query((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>, grid, block,
+                           lds, s, a, a.query_occupancy);
 }
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 static hipError_t launch_one(SimplexTag, const SimplexArgs& a, hipStream_t s) {
-    const size_t lds = simplex_lds_bytes(a);
-    hipError_t e = hipFuncSetAttribute((const void*)simplex_loop_kernel<T, VEC, MODE, KMAX, PPW>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((simplex_loop_kernel<T, VEC, MODE, KMAX, PPW>), dim3(a.nslot * a.G),
-                       dim3(64 * a.waves), lds, s, a);
-    return hipGetLastError();
+    return launch_or_query((const void*)simplex_loop_kernel<T, VEC, MODE, KMAX, PPW>,
+                           dim3(a.nslot * a.G), dim3(64 * a.waves), simplex_lds_bytes(a), s, a,
+                           a.query_occupancy);
 }
 
 template <typename Tag, typename Args, typename T, int KMAX>
@@ -776,16 +777,9 @@ static bool geometry_ok(const Args& a) {
 template <typename T, int VEC, int MODE>
 static hipError_t launch_multi_cpp(const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
-#define BMC_MULTI(C)                                                                          \
-    do {                                                                                      \
-        hipError_t e = hipFuncSetAttribute((const void*)gibbs_multi_kernel<T, VEC, MODE, C>,  \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                           (int)lds);                                         \
-        if (e != hipSuccess) return e;                                                        \
-        hipLaunchKernelGGL((gibbs_multi_kernel<T, VEC, MODE, C>), dim3(a.G), dim3(64 * a.waves), \
-                           lds, s, a);                                                        \
-        return hipGetLastError();                                                             \
-    } while (0)
+#define BMC_MULTI(C)                                                                        \
+    return launch_or_query((const void*)gibbs_multi_kernel<T, VEC, MODE, C>, dim3(a.G),     \
+                           dim3(64 * a.waves), lds, s, a, a.query_occupancy)
     switch (a.chains_per_pass) {
         case 2: BMC_MULTI(2);
         case 4: BMC_MULTI(4);
@@ -828,22 +822,15 @@ int gibbs_reg_multi_cap(int k, bool f32, int vec) {
 template <typename T, int VEC, int KMAX>
 static hipError_t launch_multi_reg_k(const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
-#define BMC_MR(C)                                                                                \
-    do {                                                                                         \
-        hipError_t e = hipFuncSetAttribute(                                                      \
-            (const void*)gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1>,                       \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        if (e != hipSuccess) return e;                                                           \
-        hipLaunchKernelGGL((gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1>), dim3(a.G),        \
-                           dim3(64 * a.waves), lds, s, a);                                       \
-        return hipGetLastError();                                                                \
-    } while (0)
+#define BMC_MR(C)                                                                            \
+    return launch_or_query((const void*)gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1>,        \
+                           dim3(a.G), dim3(64 * a.waves), lds, s, a, a.query_occupancy)
     // only the combinations that fit the 256-VGPR budget without spilling are built
     constexpr int CMAX = reg_multi_cap(KMAX, sizeof(T) == 4, VEC);
     switch (a.chains_per_pass) {
-        case 2: if constexpr (CMAX >= 2) BMC_MR(2); break;
-        case 4: if constexpr (CMAX >= 4) BMC_MR(4); break;
-        case 8: if constexpr (CMAX >= 8) BMC_MR(8); break;
+        case 2: if constexpr (CMAX >= 2) { BMC_MR(2); } break;
+        case 4: if constexpr (CMAX >= 4) { BMC_MR(4); } break;
+        case 8: if constexpr (CMAX >= 8) { BMC_MR(8); } break;
     }
 #undef BMC_MR
     return hipErrorInvalidValue;

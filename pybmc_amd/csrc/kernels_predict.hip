@@ -402,6 +402,7 @@ hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (a.ev_mid && (e = hipEventRecord(a.ev_mid, s)) != hipSuccess) return e;
     if (a.n_q > 0 || a.n_cov > 0) {
         int nsort = 64;
         while (nsort < a.S) nsort <<= 1;

@@ -35,13 +35,13 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_the_header():
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
     lib = _lib.load_library()
-    assert lib.bmc_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.bmc_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_the_header():
     # bmc_stats: 4 doubles, int64, 7 int32 (+4 pad), 2 int64 -> 8-byte aligned
     assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 8 + 8 * 4 + 2 * 8
-    assert ctypes.sizeof(_lib.Tuning) == 28
+    assert ctypes.sizeof(_lib.Tuning) == 32
 
 
 def test_missing_library_fails_loudly(monkeypatch):
