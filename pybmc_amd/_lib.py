@@ -114,6 +114,18 @@ def _share_hip_runtime_with_torch():
             pass
 
 
+def bind(path, mode=C.RTLD_GLOBAL):
+    """dlopen one build of the library and bind every prototype."""
+    lib = C.CDLL(path, mode=mode)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bmc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version mismatch")
+    return lib
+
+
 def load_library():
     """dlopen the in-tree library and bind every prototype.  Raises if absent."""
     global _lib
@@ -125,15 +137,8 @@ def load_library():
                 f"{LIB_PATH} is missing: build it with `make -C pybmc_amd/csrc` "
                 "(or __graft_entry__.build()).  pybmc_amd has no CPU fallback.")
         _share_hip_runtime_with_torch()
-        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-        for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
-            fn.restype = res
-            fn.argtypes = args
-        if lib.bmc_abi_version() != ABI_VERSION:
-            raise RuntimeError("libpybmc_amd.so ABI version mismatch")
-        _lib = lib
-        return lib
+        _lib = bind(LIB_PATH)
+        return _lib
 
 
 def _dptr(a):
@@ -147,8 +152,9 @@ class BmcError(RuntimeError):
 class Context:
     """One bmc_ctx: one GPU, one host thread at a time."""
 
-    def __init__(self, device=0):
-        self._lib = load_library()
+    def __init__(self, device=0, lib=None):
+        # `lib`: another build of the same ABI (scripts/ab.py compares builds in one process)
+        self._lib = lib if lib is not None else load_library()
         h = _P()
         rc = self._lib.bmc_create(int(device), C.byref(h))
         if rc != BMC_OK:

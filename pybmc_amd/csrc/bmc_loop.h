@@ -521,6 +521,9 @@ __device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const 
     // (one row per lane affords 16 reads in flight even with 8 chains: C5 x 8 chains 26.2 -> 23.1 us)
     constexpr int UNB = (VEC == 1 ? 128 : 64) / (CPP * VEC);
     constexpr int UN = UNB >= 16 ? 16 : UNB >= 4 ? UNB : 4;
+    // (Eight chains per pass: hipcc parks the leaders' per-iteration state in scratch around the
+    // pass -- never inside these column loops -- see spill_whitelist.txt.  Scheduling fences that
+    // bound the u values in flight remove the scratch and cost 4 %: measured, rejected.)
     double a0[CPP][VEC], a1[CPP][VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {

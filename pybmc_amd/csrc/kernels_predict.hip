@@ -215,8 +215,10 @@ __device__ __forceinline__ int sel_bin(double x, double mn, double scale) {
     return b < 0 ? 0 : (b > SEL_BINS - 1 ? SEL_BINS - 1 : b);
 }
 
+// (4 waves per SIMD = two workgroups per CU = 128 VGPRs, enough for up to 24 draws per thread;
+// 32 draws per thread -- 12289..16384 draws -- take the 256-VGPR budget instead of spilling)
 template <int VPT>
-__global__ __launch_bounds__(SEL_THREADS, 4) void predict_select_kernel(
+__global__ __launch_bounds__(SEL_THREADS, VPT > 24 ? 2 : 4) void predict_select_kernel(
     const double* __restrict__ R, int32_t S, int32_t S_pad, int64_t M,
     const int32_t* __restrict__ q_index, const double* __restrict__ q_gamma, int32_t n_q,
     const double* __restrict__ truth, const int32_t* __restrict__ cov_lo,
