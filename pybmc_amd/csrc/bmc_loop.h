@@ -1,6 +1,8 @@
 // Building blocks shared by the persistent loop kernels (Gibbs and simplex samplers):
 // on-chip panel store, XCD placement check, group all-reduce of the partial rss.
 #pragma once
+#include <utility>
+
 #include "bmc_dev.h"
 #include "bmc_launch.h"
 
@@ -215,6 +217,39 @@ __device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* _
     return s;
 }
 
+// ---- u_j as an FMA operand without an LDS read per column ---------------------------------
+// The residual pass needs u_j, the same value in all 64 lanes, for every column j.  Read from
+// LDS at a lane-uniform address that is one ds_read per column and wave (2 LDS cycles per
+// double): with 5 waves x 32 columns per CU the pass was bound by the LDS pipe (~320 cycles),
+// not by its 32 FMAs (128).  Instead every wave loads u ONCE, lane l <- u[16 r + (l & 15)] in
+// register r (one conflict-free ds_read_b64 per 16 columns), and the FMA takes its operand
+// through DPP: v_fmac_f64_dpp ... row_newbcast:n hands every lane the value held by lane n of
+// its own 16-lane row (the only DPP control 64-bit operations have on gfx950).  No LDS read and
+// no extra VALU instruction per column; operands and operation order are unchanged, so the
+// bits of the chain are unchanged (acc + u * (-x) == fma(-x, u, acc)).
+// `FIRST`: the statement opens with the two wait states a DPP read needs after a VALU write of
+// its source (hipcc does not see into the asm, cdna guide 5.7 item 2; u normally comes straight
+// from the LDS read, but a compiler copy right in front of the statement must be safe too).
+template <int N, bool FIRST>
+__device__ __forceinline__ void fmac_rowbcast_neg(double& acc, double u_rows, double x) {
+    static_assert(N >= 0 && N < 16, "lane within a row");
+    if constexpr (FIRST)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc) : "v"(u_rows), "v"(x), "n"(N));
+    else
+        asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc) : "v"(u_rows), "v"(x), "n"(N));
+}
+
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // A value the compiler must re-read from its register at this point: keeps f32 panel data
 // as f32 VGPRs (one register per element) instead of hoisting the f32->f64 conversion out
 // of the iteration loop, which would double the register footprint.
@@ -355,25 +390,54 @@ struct PanelStore {
         double s = 0.0;
         if constexpr (MODE == MODE_REG) {
             double acc[PPW][VEC][4];
+            // u through DPP row broadcasts (fmac_rowbcast_neg above) from 16 columns on: register
+            // r of this wave holds u[16 r .. 16 r + 15], repeated in its four rows of 16 lanes.
+            // (8 columns: the few LDS reads are not the bound, and the DPP form costs half a
+            // cycle per FMA more -- measured 3 % slower for notebook-sized single-workgroup
+            // chains.)  The in-place DPP form needs its four accumulators initialised by register
+            // copies first; with several rows per lane (PPW * VEC > 1: 4 copies per row) the
+            // first FMA of each chain keeps the three-operand form with u from an LDS broadcast
+            // read instead, which takes its start value (y or 0) as an operand.  One row per
+            // lane: all columns through DPP (C2: 1.135 vs 1.165 us per iteration).
+            constexpr bool USE_DPP = KMAX >= 16;
+            constexpr int JD = !USE_DPP ? KMAX : (PPW * VEC > 1 ? 4 : 0);   // first DPP column
+            if constexpr (JD == 0) {
 #pragma unroll
-            for (int i = 0; i < PPW; ++i)
+                for (int i = 0; i < PPW; ++i)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    acc[i][v][0] = (double)yr[i][v];
-                    acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
-                }
+                    for (int v = 0; v < VEC; ++v) {
+                        acc[i][v][0] = (double)yr[i][v];
+                        acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
+                    }
+            }
 #pragma unroll
-            for (int j = 0; j < KMAX; j += 4) {
+            for (int j = 0; j < JD; j += 4) {
                 const double u0 = u_lds[j], u1 = u_lds[j + 1], u2 = u_lds[j + 2], u3 = u_lds[j + 3];
 #pragma unroll
                 for (int i = 0; i < PPW; ++i)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        acc[i][v][0] = fma(-as_f64_in_loop(xr[i][j][v]), u0, acc[i][v][0]);
-                        acc[i][v][1] = fma(-as_f64_in_loop(xr[i][j + 1][v]), u1, acc[i][v][1]);
-                        acc[i][v][2] = fma(-as_f64_in_loop(xr[i][j + 2][v]), u2, acc[i][v][2]);
-                        acc[i][v][3] = fma(-as_f64_in_loop(xr[i][j + 3][v]), u3, acc[i][v][3]);
+                        acc[i][v][0] = fma(-as_f64_in_loop(xr[i][j][v]), u0,
+                                           j == 0 ? (double)yr[i][v] : acc[i][v][0]);
+                        acc[i][v][1] = fma(-as_f64_in_loop(xr[i][j + 1][v]), u1, j == 0 ? 0.0 : acc[i][v][1]);
+                        acc[i][v][2] = fma(-as_f64_in_loop(xr[i][j + 2][v]), u2, j == 0 ? 0.0 : acc[i][v][2]);
+                        acc[i][v][3] = fma(-as_f64_in_loop(xr[i][j + 3][v]), u3, j == 0 ? 0.0 : acc[i][v][3]);
                     }
+            }
+            if constexpr (USE_DPP) {
+                constexpr int NU = (KMAX + 15) / 16;
+                double urow[NU];
+#pragma unroll
+                for (int r = 0; r < NU; ++r) urow[r] = u_lds[r * 16 + (lane & 15)];
+                static_for<KMAX - JD>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value + JD;
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            fmac_rowbcast_neg<j % 16, (j == JD || j % 16 == 0)>(
+                                acc[i][v][j % 4], urow[j / 16], as_f64_in_loop(xr[i][j][v]));
+                });
             }
 #pragma unroll
             for (int i = 0; i < PPW; ++i)

@@ -40,6 +40,35 @@
 
 namespace bmc {
 
+// u_j | sigma2 with sigma2 = sp / g (the beta | sigma2 draw of inference_utils.py:41-45 in the
+// basis of bmc_set_prior):  D = lam g + sp, r = rsqrt(D), d_j = sp r^2,
+//   u_j = r^2 (c1 sp + c2 g) + sqrt(sp) r xi.
+// sqrt(sp) is taken as sp * rsqrt(sp) right here, beside rsqrt(D): two independent
+// v_rsq_f64 + one Newton step each, which the in-order pipeline overlaps, instead of a full
+// sqrt (rsq + two Newton steps + range scaling, ~14 dependent f64 operations) at the end of the
+// previous iteration's sigma2 step, all of it on the serial path.
+__device__ __forceinline__ double draw_u(double lam, double c1, double c2, double xi, double sp,
+                                         double g, double sq_sp_unused) {
+#ifndef BMC_SQRT_SEPARATE
+    (void)sq_sp_unused;
+    const double D = fma(lam, g, sp);
+    const double r = rsqrt(D);
+    const double rs = rsqrt(sp);
+    const double m = fma(c2, g, c1 * sp);
+    return fma(r * r, m, ((sp * rs) * r) * xi);
+#else
+    const double D = fma(lam, g, sp);
+    const double r = rsqrt(D);
+    const double m = fma(c2, g, c1 * sp);
+    return fma(r * r, m, (sq_sp_unused * r) * xi);
+#endif
+}
+#ifndef BMC_SQRT_SEPARATE
+#define BMC_SQRT_OF(x) 0.0     /* not used: draw_u takes sqrt(sp) as sp * rsqrt(sp) */
+#else
+#define BMC_SQRT_OF(x) sqrt(x)
+#endif
+
 // PACK: the same kernel held to 128 VGPRs (4 waves per SIMD), so that two 5-wave groups of
 // different chains fit a CU side by side whatever SIMDs their waves land on -- used when more
 // than 8 chains share a launch (two per XCD).  It exists only for shapes with one panel of at
@@ -108,7 +137,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
     // which makes the recording wave wait for ITS stores of the previous iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), other counters untouched
     // sigma2 = sp_eff / g_eff; starts at the OLS value (inference_utils.py:37)
-    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
+    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = BMC_SQRT_OF(a.sigma2_init);
     double xi_next[KCH], lam_r[KCH], c1_r[KCH], c2_r[KCH];
     double gam_next = 0.0;
     if (wave == 0) {
@@ -135,12 +164,8 @@ void gibbs_loop_kernel(GibbsArgs a) {
 #pragma unroll
             for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
-                if (ch * 64 < K && j < K) {
-                    const double D = fma(lam_r[ch], g_eff, sp_eff);
-                    const double r = rsqrt(D);
-                    const double m = fma(c2_r[ch], g_eff, c1_r[ch] * sp_eff);
-                    u_lds[j] = fma(r * r, m, (sq_sp * r) * xi_next[ch]);
-                }
+                if (ch * 64 < K && j < K)
+                    u_lds[j] = draw_u(lam_r[ch], c1_r[ch], c2_r[ch], xi_next[ch], sp_eff, g_eff, sq_sp);
             }
         }
         STAMP(0);
@@ -210,7 +235,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
                 const bool floor_hit = scale_post < 1e-6 * gam_t;
                 sp_eff = floor_hit ? 1e-6 : scale_post;
                 g_eff = floor_hit ? 1.0 : gam_t;
-                sq_sp = sqrt(sp_eff);
+                sq_sp = BMC_SQRT_OF(sp_eff);
                 if (lane == 0) { ctl[0] = sp_eff; ctl[3] = g_eff; }
             }
             STAMP(6);
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     double* u_mine = u_lds + (size_t)chain * kpad;
 
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see gibbs_loop_kernel
-    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
+    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = BMC_SQRT_OF(a.sigma2_init);
     double xi_next[KCH], lam_r[KCH], c1_r[KCH], c2_r[KCH];
     double gam_next = 0.0;
     if (leader) {
@@ -308,10 +333,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                 const int j = ch * 64 + lane;
                 u_rec[ch] = 0.0;
                 if (ch * 64 < K && j < K) {
-                    const double D = fma(lam_r[ch], g_eff, sp_eff);
-                    const double r = rsqrt(D);
-                    const double m = fma(c2_r[ch], g_eff, c1_r[ch] * sp_eff);
-                    u_rec[ch] = fma(r * r, m, (sq_sp * r) * xi_next[ch]);
+                    u_rec[ch] = draw_u(lam_r[ch], c1_r[ch], c2_r[ch], xi_next[ch], sp_eff, g_eff, sq_sp);
                     u_mine[j] = u_rec[ch];
                 }
             }
@@ -379,7 +401,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                 const bool floor_hit = scale_post < 1e-6 * gam_t;
                 sp_eff = floor_hit ? 1e-6 : scale_post;
                 g_eff = floor_hit ? 1.0 : gam_t;
-                sq_sp = sqrt(sp_eff);
+                sq_sp = BMC_SQRT_OF(sp_eff);
             }
         }
         GSTAMP(6);
@@ -423,18 +445,13 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
     const double c2 = act ? a.c2[lane] : 0.0, u0 = act ? a.u0[lane] : 0.0;
     const double g0x2 = act ? 2.0 * a.g0[lane] : 0.0;
     d_lds[lane] = 0.0;
-    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = sqrt(a.sigma2_init);
+    double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = BMC_SQRT_OF(a.sigma2_init);
     double xi_next = (act && T_it > 0) ? xi[lane] : 0.0;
     double gam_next = T_it > 0 ? gam[0] : 1.0;
     for (int64_t t = 0; t < T_it; ++t) {
         // u | sigma2, the operations of gibbs_loop_kernel
         double u = 0.0;
-        if (act) {
-            const double D = fma(lam, g_eff, sp_eff);
-            const double r = rsqrt(D);
-            const double m = fma(c2, g_eff, c1 * sp_eff);
-            u = fma(r * r, m, (sq_sp * r) * xi_next);
-        }
+        if (act) u = draw_u(lam, c1, c2, xi_next, sp_eff, g_eff, sq_sp);
         const double sp_rec = sp_eff, g_rec = g_eff;
         const double gam_t = gam_next;
         if (t + 1 < T_it) {
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
         const bool floor_hit = scale_post < 1e-6 * gam_t;
         sp_eff = floor_hit ? 1e-6 : scale_post;
         g_eff = floor_hit ? 1.0 : gam_t;
-        sq_sp = sqrt(sp_eff);
+        sq_sp = BMC_SQRT_OF(sp_eff);
     }
     if (lane == 0 && T_it > 0) uout[(T_it - 1) * (K + 1) + K] = sqrt(sp_eff / g_eff);
 }

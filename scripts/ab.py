@@ -78,7 +78,9 @@ def main():
         times = {name: [] for name, _ in ctxs}
         first = None
         for r in range(args.rounds):
-            for name, c in ctxs:
+            # rotate the order: the first build timed after a pause gets a slightly higher clock
+            order = ctxs[r % len(ctxs):] + ctxs[:r % len(ctxs)]
+            for name, c in order:
                 out, st = c.gibbs_run(chains, iters, seeds=np.arange(chains) + 1)
                 times[name].append(st["loop_ms"] * 1e3 / iters)
                 if first is None:
