@@ -127,7 +127,10 @@ __device__ __forceinline__ bool granule_gather1(const gu64* gp, int n2, unsigned
 __device__ __forceinline__ double granule_sum1(gu64 x, int lane) {
     const int w = (int)(unsigned)x;
     const int other = __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true);
-    double v = (lane & 1) == 0 ? __hiloint2double(w, other) : __hiloint2double(other, w);
+    // even lane: (hi, lo) = (w, other); odd lane: (other, w).  Branch-free (xor swap under a
+    // lane-parity mask): as a ?: hipcc built it from exec-mask branches on the serial path.
+    const int swap = (w ^ other) & -(lane & 1);
+    double v = __hiloint2double(w ^ swap, other ^ swap);
     v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
     v += dpp_mov_f64<0x141>(v);         // row_half_mirror
     v += dpp_mov_f64<0x140>(v);         // row_mirror

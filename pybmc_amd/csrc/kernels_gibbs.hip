@@ -47,13 +47,25 @@ namespace bmc {
 // v_rsq_f64 + one Newton step each, which the in-order pipeline overlaps, instead of a full
 // sqrt (rsq + two Newton steps + range scaling, ~14 dependent f64 operations) at the end of the
 // previous iteration's sigma2 step, all of it on the serial path.
+// 1/sqrt(x) for finite x > 0: v_rsq_f64 and one Newton step, the arithmetic of the library
+// rsqrt() without its tests for 0 / inf / nan arguments (D and sp are sums of positive terms).
+__device__ __forceinline__ double rsqrt_pos(double x) {
+#ifdef BMC_LIB_RSQRT
+    return rsqrt(x);
+#else
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y0, y0, 1.0);           // 1 - x y0^2
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);       // y0 (1 + e/2 + 3 e^2 / 8)
+#endif
+}
+
 __device__ __forceinline__ double draw_u(double lam, double c1, double c2, double xi, double sp,
                                          double g, double sq_sp_unused) {
 #ifndef BMC_SQRT_SEPARATE
     (void)sq_sp_unused;
     const double D = fma(lam, g, sp);
-    const double r = rsqrt(D);
-    const double rs = rsqrt(sp);
+    const double r = rsqrt_pos(D);
+    const double rs = rsqrt_pos(sp);
     const double m = fma(c2, g, c1 * sp);
     return fma(r * r, m, ((sp * rs) * r) * xi);
 #else

@@ -12,7 +12,7 @@ p = synth_problem(10000, 33, 32, 0)
 ctx.set_problem(p["y"], p["X"]); ctx.set_prior(*p["prior"])
 names = ["u", "B1", "matvec", "wsum", "B2+wavesum", "pub+poll", "s2", "top", "gsum", "polls"]
 T = 20000
-cfgs = [(32, 5, 1, 1, 0), (32, 5, 1, 1, 1), (20, 8, 1, 1, 0), (32, 5, 2, 0, 0)]
+cfgs = [(0, 0, 0, 0, 0), (32, 5, 1, 1, 0), (32, 4, 1, 2, 0), (20, 8, 1, 1, 0)]
 for G, W, res, ppw, agent in cfgs:
     ctx.set_tuning(G, W, res, ppw, agent)
     ctx.gibbs_run(1, 2000, seeds=[1])
