@@ -31,6 +31,7 @@ from pybmc.inference_utils import (  # noqa: E402
     gibbs_sampler, gibbs_sampler_simplex, USVt_hat_extraction)
 from pybmc.sampling_utils import coverage, rndm_m_random_calculator  # noqa: E402
 from pybmc.bmc import BayesianModelCombination  # noqa: E402
+from pybmc.data import Dataset  # noqa: E402
 
 
 @contextlib.contextmanager
@@ -119,7 +120,85 @@ def gibbs_case(name, y, X, prior, T, seed_z, seed_g, store_inputs=True, extra=No
     print(name, samples.shape, "mean sigma", samples[:, -1].mean())
 
 
+def standin_csv(path):
+    """A small table shaped like the nuclear-mass file the reference's docs load
+    (selected_data.h5 is absent from the reference checkout): long format, one row per
+    (model, N, Z) with two properties.  Models cover slightly different (N, Z) sets so the
+    inner join of load_data (pybmc/data.py:121-125) has something to drop."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    rows = []
+    grid = [(n, z) for z in range(20, 32) for n in range(z, z + 12)]
+    for mi, model in enumerate(["truth", "FRDM", "HFB24", "UNEDF1", "SKM"]):
+        for (n, z) in grid:
+            if (n * 7 + z * 3 + mi) % 11 == 0 and model != "truth":
+                continue                                   # this model lacks that nucleus
+            be = 8.5 * (n + z) - 0.1 * (n - z) ** 2
+            rad = 1.2 * (n + z) ** (1.0 / 3.0)
+            rows.append((model, n, z, round(be + (0.0 if mi == 0 else rng.normal(0.2 * mi, 0.8)), 6),
+                         round(rad + (0.0 if mi == 0 else rng.normal(0.0, 0.02)), 6)))
+    order = rng.permutation(len(rows))                     # rows in no particular order
+    df = pd.DataFrame([rows[i] for i in order], columns=["model", "N", "Z", "BE", "Rad"])
+    df.to_csv(path, index=False)
+    return df
+
+
+def dataset_case():
+    """f4: the reference's Dataset (pybmc/data.py) on the committed stand-in CSV: loading and
+    alignment (:30-129), the overview (:131-192), both splits (:247-330, random_state = 1),
+    the distance split on its own (:194-245) and the subset filters (:332-374)."""
+    path = os.path.join(HERE, "dataset_standin.csv")
+    standin_csv(path)
+    models = ["truth", "FRDM", "HFB24", "UNEDF1", "SKM"]
+    ds = Dataset(path)
+    data = ds.load_data(models, keys=["BE", "Rad"], domain_keys=["N", "Z"])
+    out = {}
+    for prop, df in data.items():
+        out[f"load_{prop}_columns"] = np.array(list(df.columns))
+        out[f"load_{prop}_values"] = df.to_numpy(float)
+        out[f"load_{prop}_index"] = df.index.to_numpy()
+    view = ds.view_data()
+    out["view_properties"] = np.array(view["available_properties"])
+    out["view_models"] = np.array(view["available_models"])
+    out["view_model_BE"] = ds.view_data(model_name="FRDM")["BE"].to_numpy(float)
+    out["view_series"] = ds.view_data("Rad", "SKM").to_numpy(float)
+    tr, va, te = ds.split_data(data, "BE", splitting_algorithm="random",
+                               train_size=0.6, val_size=0.2, test_size=0.2)
+    out["random_train"], out["random_val"], out["random_test"] = (
+        tr.index.to_numpy(), va.index.to_numpy(), te.index.to_numpy())
+    out["random_train_values"] = tr.to_numpy(float)
+    # the distance split measures against ALL columns of the frame (data.py:276), so it is
+    # given a frame of the two domain columns
+    dom = {"dom": data["BE"][["N", "Z"]]}
+    stable = [(26, 24), (30, 28), (34, 30)]
+    tr, va, te = ds.split_data(dom, "dom", splitting_algorithm="inside_to_outside",
+                               stable_points=stable, distance1=2.0, distance2=4.5)
+    out["dist_train"], out["dist_val"], out["dist_test"] = (
+        tr.index.to_numpy(), va.index.to_numpy(), te.index.to_numpy())
+    pts = [tuple(r) for r in data["BE"][["N", "Z"]].to_numpy()[:60]]
+    a, b, c = ds.separate_points_distance_allSets(pts, stable, 1.5, 3.0)
+    out["sep_a"], out["sep_b"], out["sep_c"] = np.array(a), np.array(b), np.array(c)
+    subsets = {
+        "range": dict(filters={"Z": (22, 27)}),
+        "list": dict(filters={"N": [24, 25, 30, 41]}),
+        "value": dict(filters={"Z": 25}),
+        "callable": dict(filters={"N": lambda s: s % 2 == 0}),
+        "multi": dict(filters={"multi": lambda r: r["N"] - r["Z"] >= 6, "Z": (21, 30)}),
+        "models": dict(filters={"Z": (20, 24)}, models_to_include=["FRDM", "SKM", "nope"]),
+    }
+    for name, kw in subsets.items():
+        sub = ds.get_subset("BE", **kw)
+        out[f"subset_{name}_index"] = sub.index.to_numpy()
+        out[f"subset_{name}_columns"] = np.array(list(sub.columns))
+        out[f"subset_{name}_values"] = sub.to_numpy(float)
+    np.savez_compressed(os.path.join(HERE, "dataset_standin.npz"), **out)
+    print("dataset_standin", {k: v.shape for k, v in out.items() if k.startswith("load")})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        dataset_case()
+        return
+    dataset_case()
     # ---- G1: the reference's own tiny test (tests/test_inference_utils.py:6-14)
     y = np.array([1.0, 2.0, 3.0])
     X = np.array([[1, 0], [0, 1], [1, 1]])
