@@ -111,7 +111,12 @@ def profiled_traffic(kernel_substr):
     try:
         with open(files[-1]) as f:
             summ = json.load(f)
-        for name, e in summ["kernels"].items():
+        names = list(summ["kernels"])
+        if summ.get("headline") in summ["kernels"]:     # the headline step's dominant kernel first
+            names.remove(summ["headline"])
+            names.insert(0, summ["headline"])
+        for name in names:
+            e = summ["kernels"][name]
             if kernel_substr in name and "hbm_read_bytes_per_launch" in e:
                 return {"bytes_per_launch": e["hbm_read_bytes_per_launch"]
                         + e.get("hbm_write_bytes_per_launch", 0.0),

@@ -68,9 +68,17 @@ hipError_t launch_panelize(const void* Xsrc, const void* ysrc, int64_t n, int32_
 // row = (l>>4) + 4*reg.  For G tile (ti,tj): A[i][k] = a[n0+k][16ti+i],
 // B[k][j] = a[n0+k][16tj+j].
 constexpr int GRAM_LDR = 66;
-constexpr int GRAM_TPW = 8;  // tile pairs per wave
 
-template <typename T>
+// Staging: the next sub-panel travels global -> registers while the MFMAs of the current one
+// run (one LDS buffer: at K = 256 a 64-row sub-panel of all 272 columns is 140 KiB), then
+// registers -> LDS between two barriers.  Each thread moves NV two-row pieces (16 B of f64,
+// 8 B of f32): piece e = (column e / 32, rows 2 (e % 32), +1), so 32 consecutive threads read
+// 512 contiguous bytes of one column.  (The first version staged with a scalar loop straight
+// into LDS in front of the MFMAs: 68 dependent-latency loads per thread and sub-panel, nothing
+// overlapped -- 12 % MFMA busy at C5.)
+template <typename T> struct Pair2 { T a, b; };
+
+template <typename T, int TPW, int NV>
 __global__ __launch_bounds__(256) void gram_mfma_kernel(
     const T* __restrict__ X, const T* __restrict__ y, int32_t K, int32_t RP, int32_t nsub,
     int32_t subs_per_chunk, int32_t Ka_pad, int32_t ntile, int32_t npairs,
@@ -80,11 +88,11 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = blockIdx.x;
-    const int pair0 = (blockIdx.y * 4 + wave) * GRAM_TPW;
+    const int pair0 = (blockIdx.y * 4 + wave) * TPW;
 
-    int ti[GRAM_TPW], tj[GRAM_TPW];
+    int ti[TPW], tj[TPW];
 #pragma unroll
-    for (int q = 0; q < GRAM_TPW; ++q) {
+    for (int q = 0; q < TPW; ++q) {
         // pair id -> (ti, tj), tj >= ti, row-by-row enumeration of the upper triangle
         int id = pair0 + q, a = 0, rowlen = ntile;
         if (id >= npairs) id = 0;
@@ -92,31 +100,51 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(
         ti[q] = a;
         tj[q] = a + id;
     }
-    f64x4 acc[GRAM_TPW];
+    f64x4 acc[TPW];
 #pragma unroll
-    for (int q = 0; q < GRAM_TPW; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < TPW; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     const int s_begin = chunk * subs_per_chunk;
     int s_end = s_begin + subs_per_chunk;
     if (s_end > nsub) s_end = nsub;
     const int kq = lane >> 4, cl = lane & 15;
-    for (int s = s_begin; s < s_end; ++s) {
+    const int npiece = Ka_pad * 32;
+
+    Pair2<T> stage[NV];
+    auto fetch = [&](int s) {
         const int64_t row0 = (int64_t)s * 64;
         const int64_t p = row0 / RP;
         const int32_t r0 = (int32_t)(row0 - p * RP);
-        for (int e = tid; e < Ka_pad * 64; e += 256) {
-            const int a = e >> 6, r = e & 63;
-            double v = 0.0;
-            if (a < K) v = (double)X[(p * K + a) * RP + r0 + r];
-            else if (a == K) v = (double)y[row0 + r];
-            tile[a * GRAM_LDR + r] = v;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256;
+            const int a = e >> 5, r = (e & 31) * 2;
+            Pair2<T> v{(T)0, (T)0};
+            if (e < npiece) {
+                if (a < K) v = *reinterpret_cast<const Pair2<T>*>(&X[(p * K + a) * RP + r0 + r]);
+                else if (a == K) v = *reinterpret_cast<const Pair2<T>*>(&y[row0 + r]);
+            }
+            stage[i] = v;
+        }
+    };
+    if (s_begin < s_end) fetch(s_begin);
+    for (int s = s_begin; s < s_end; ++s) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256;
+            if (e < npiece) {
+                double* d = &tile[(e >> 5) * GRAM_LDR + (e & 31) * 2];
+                d[0] = (double)stage[i].a;
+                d[1] = (double)stage[i].b;
+            }
         }
         __syncthreads();
+        if (s + 1 < s_end) fetch(s + 1);   // in flight under the MFMAs below
 #pragma unroll 4
         for (int kk = 0; kk < 16; ++kk) {
             const int rr = kk * 4 + kq;
 #pragma unroll
-            for (int q = 0; q < GRAM_TPW; ++q) {
+            for (int q = 0; q < TPW; ++q) {
                 if (pair0 + q < npairs) {  // wave-uniform
                     const double a = tile[(16 * ti[q] + cl) * GRAM_LDR + rr];
                     const double b = tile[(16 * tj[q] + cl) * GRAM_LDR + rr];
@@ -128,7 +156,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(
     }
     double* out = partial + (size_t)chunk * Ka_pad * Ka_pad;
 #pragma unroll
-    for (int q = 0; q < GRAM_TPW; ++q) {
+    for (int q = 0; q < TPW; ++q) {
         if (pair0 + q < npairs) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -140,20 +168,34 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(
     }
 }
 
-// Sum the chunk partials in chunk order (bit-reproducible), mirror to the lower triangle.
+// Sum the chunk partials (bit-reproducible: fixed order), mirror to the lower triangle.  Four
+// threads per element each sum a quarter of the chunks in chunk order, then
+// (q0 + q1) + (q2 + q3): a dependent chain of nchunk / 4 additions instead of nchunk.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial,
                                                           int32_t nchunk, int32_t Ka,
                                                           int32_t Ka_pad,
                                                           double* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= Ka * Ka) return;
-    const int i = e / Ka, j = e % Ka;
-    if (i > j) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = gid >> 2, part = gid & 3;
+    const bool live = e < Ka * Ka;
+    const int i = live ? e / Ka : 0, j = live ? e % Ka : 0;
+    const int per = (nchunk + 3) / 4;
+    const int c0 = part * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
     double s = 0.0;
-    for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * Ka_pad * Ka_pad + (size_t)i * Ka_pad + j];
-    out[(size_t)i * Ka + j] = s;
-    out[(size_t)j * Ka + i] = s;
+    if (live && i <= j)
+        for (int c = c0; c < c1; ++c)
+            s += partial[(size_t)c * Ka_pad * Ka_pad + (size_t)i * Ka_pad + j];
+    const double s01 = s + __shfl_xor(s, 1);       // lanes 0,1 -> q0 + q1; lanes 2,3 -> q2 + q3
+    const double lo = __shfl(s01, (threadIdx.x & 60), 64), hi = __shfl(s01, (threadIdx.x & 60) + 2, 64);
+    if (live && i <= j && part == 0) {
+        const double t = lo + hi;
+        out[(size_t)i * Ka + j] = t;
+        out[(size_t)j * Ka + i] = t;
+    }
 }
+
+// tile pairs per wave: 8, or 16 for wide problems (fewer workgroups re-stage the same rows)
+static int gram_tpw(int npairs) { return npairs > 64 ? 16 : 8; }
 
 static void gram_geometry(const Panels& P, int& Ka_pad, int& ntile, int& npairs, int& nsub,
                           int& nchunk, int& spc) {
@@ -161,11 +203,21 @@ static void gram_geometry(const Panels& P, int& Ka_pad, int& ntile, int& npairs,
     ntile = Ka_pad / 16;
     npairs = ntile * (ntile + 1) / 2;
     nsub = P.npanels * P.vec;  // 64-row sub-panels
-    nchunk = nsub < 512 ? nsub : 512;
-    // keep the scratch below ~256 MB for wide problems
+    // sub-panels per chunk: the workgroups (chunks x pair groups) run in rounds of one per CU;
+    // take the chunking whose rounds x sub-panels-per-chunk is least (few, full rounds), with
+    // enough chunks to fill the chip and the partial slabs below ~256 MB
+    const int pgroups = (npairs + 4 * gram_tpw(npairs) - 1) / (4 * gram_tpw(npairs));
     const size_t per = (size_t)Ka_pad * Ka_pad * 8;
-    while (nchunk > 1 && per * nchunk > ((size_t)256 << 20)) nchunk = (nchunk + 1) / 2;
-    spc = (nsub + nchunk - 1) / nchunk;
+    long best_cost = -1;
+    spc = 1;
+    for (int c = 1; c <= 64; ++c) {
+        const long chunks = (nsub + c - 1) / c;
+        if (per * (size_t)chunks > ((size_t)256 << 20) && c < 64) continue;
+        const long rounds = (chunks * pgroups + 255) / 256;
+        const long cost = rounds * c;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; spc = c; }   // ties: fewer slabs
+        if (chunks * pgroups <= 256) break;   // one round already: larger chunks only idle CUs
+    }
     nchunk = (nsub + spc - 1) / spc;
 }
 
@@ -175,32 +227,42 @@ size_t gram_scratch_bytes(const Panels& P) {
     return (size_t)nchunk * Ka_pad * Ka_pad * sizeof(double);
 }
 
+template <typename T, int TPW, int NV>
+static hipError_t launch_gram_t(const Panels& P, dim3 grid, size_t lds, int nsub, int spc, int Ka_pad,
+                                int ntile, int npairs, void* scratch, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void*)gram_mfma_kernel<T, TPW, NV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gram_mfma_kernel<T, TPW, NV>), grid, dim3(256), lds, s, (const T*)P.X,
+                       (const T*)P.y, P.k, 64 * P.vec, nsub, spc, Ka_pad, ntile, npairs,
+                       (double*)scratch);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_gram_k(const Panels& P, dim3 grid, size_t lds, int nsub, int spc, int Ka_pad,
+                                int ntile, int npairs, int tpw, void* scratch, hipStream_t s) {
+    // NV = two-row pieces per thread: Ka_pad * 32 / 256
+    if (Ka_pad <= 48) return launch_gram_t<T, 8, 6>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
+    if (Ka_pad <= 128 && tpw == 8)
+        return launch_gram_t<T, 8, 16>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
+    if (tpw == 8) return launch_gram_t<T, 8, 34>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
+    return launch_gram_t<T, 16, 34>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
+}
+
 hipError_t launch_gram(const Panels& P, void* scratch, double* gram_out, hipStream_t s) {
     int Ka_pad, ntile, npairs, nsub, nchunk, spc;
     gram_geometry(P, Ka_pad, ntile, npairs, nsub, nchunk, spc);
-    const int pgroups = (npairs + 4 * GRAM_TPW - 1) / (4 * GRAM_TPW);
+    if (Ka_pad > 272) return hipErrorInvalidValue;
+    const int tpw = gram_tpw(npairs);
+    const int pgroups = (npairs + 4 * tpw - 1) / (4 * tpw);
     const size_t lds = (size_t)Ka_pad * GRAM_LDR * sizeof(double);
-    const int RP = 64 * P.vec;
-    hipError_t e;
-    if (P.f32) {
-        e = hipFuncSetAttribute((const void*)gram_mfma_kernel<float>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(gram_mfma_kernel<float>, dim3(nchunk, pgroups), dim3(256), lds, s,
-                           (const float*)P.X, (const float*)P.y, P.k, RP, nsub, spc, Ka_pad,
-                           ntile, npairs, (double*)scratch);
-    } else {
-        e = hipFuncSetAttribute((const void*)gram_mfma_kernel<double>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(gram_mfma_kernel<double>, dim3(nchunk, pgroups), dim3(256), lds, s,
-                           (const double*)P.X, (const double*)P.y, P.k, RP, nsub, spc, Ka_pad,
-                           ntile, npairs, (double*)scratch);
-    }
-    e = hipGetLastError();
+    const dim3 grid(nchunk, pgroups);
+    hipError_t e = P.f32 ? launch_gram_k<float>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, tpw, scratch, s)
+                         : launch_gram_k<double>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, tpw, scratch, s);
     if (e != hipSuccess) return e;
     const int Ka = P.k + 1;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((Ka * Ka + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((4 * Ka * Ka + 255) / 256), dim3(256), 0, s,
                        (const double*)scratch, nchunk, Ka, Ka_pad, gram_out);
     return hipGetLastError();
 }

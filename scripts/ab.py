@@ -42,6 +42,10 @@ CASES = {   # name: (problem factory, dtype, chains, iterations)
     "n100k": (lambda: dense(100000, 32, np.float64), np.float64, 1, 5000),
     "n100kx8": (lambda: dense(100000, 32, np.float64), np.float64, 8, 2000),
     "small": (lambda: synth(629, 3), np.float64, 1, 50000),
+    # chains = 0: time the one-off Gram [X y]'[X y] (f64 MFMA) instead of the loop, us per launch
+    "gram_c2": (lambda: synth(10000, 32), np.float64, 0, 50),
+    "gram_c4": (lambda: dense(200000, 64, np.float32), np.float32, 0, 20),
+    "gram_c5": (lambda: dense(50000, 256, np.float64), np.float64, 0, 20),
     "small300": (lambda: synth(629, 3), np.float64, 300, 20000),
 }
 
@@ -73,7 +77,8 @@ def main():
             c.set_prior(*prior)
             if args.groups or args.waves:
                 c.set_tuning(args.groups, args.waves)
-            c.gibbs_run(chains, max(50, iters // 20), seeds=np.arange(chains) + 1)   # warm
+            if chains:
+                c.gibbs_run(chains, max(50, iters // 20), seeds=np.arange(chains) + 1)   # warm
             ctxs.append((name, c))
         times = {name: [] for name, _ in ctxs}
         first = None
@@ -81,8 +86,13 @@ def main():
             # rotate the order: the first build timed after a pause gets a slightly higher clock
             order = ctxs[r % len(ctxs):] + ctxs[:r % len(ctxs)]
             for name, c in order:
-                out, st = c.gibbs_run(chains, iters, seeds=np.arange(chains) + 1)
-                times[name].append(st["loop_ms"] * 1e3 / iters)
+                if not chains:
+                    times[name].append(c.gram_bench(reps=iters) * 1e3)
+                    out, st = c.gram(), {"groups_per_chain": 0, "waves_per_group": 0,
+                                         "chains_per_pass": 0, "residency": 0}
+                else:
+                    out, st = c.gibbs_run(chains, iters, seeds=np.arange(chains) + 1)
+                    times[name].append(st["loop_ms"] * 1e3 / iters)
                 if first is None:
                     first = out
                 elif not np.array_equal(out, first):
