@@ -514,13 +514,17 @@ def extras(ctx, torch, dev, local_rank, N, K, T):
             if tag == "loop_c5":
                 # the one-off f64 MFMA Gram at the C5 shape (set-up row a1)
                 ms = cl.gram_bench(reps=20)
-                fl = 2.0 * n4 * (k4 + 1) ** 2
-                extra["gram_c5"] = {"ms_per_launch_pair": ms, "flops": fl,
-                                    "TFLOPs": fl / (ms * 1e-3) / 1e12,
-                                    "frac_of_78.6TF_f64_matrix_peak": fl / (ms * 1e-3) / 1e12 / 78.6,
-                                    "bytes_read": bl, "GBs": bl / (ms * 1e-3) / 1e9,
-                                    "note": "[X y]'[X y] with v_mfma_f64_16x16x4_f64, full square "
-                                            "(symmetry not exploited), gram_mfma_kernel + gram_reduce_kernel"}
+                ka_pad = -(-(k4 + 1) // 16) * 16
+                npairs = (ka_pad // 16) * (ka_pad // 16 + 1) // 2       # upper-triangle tiles
+                fl_exec = npairs * 2.0 * 256 * (-(-n4 // 64) * 64)      # what the MFMAs execute
+                extra["gram_c5"] = {"ms_per_launch_pair": ms, "flops_executed": fl_exec,
+                                    "flops_full_square": 2.0 * n4 * (k4 + 1) ** 2,
+                                    "TFLOPs_executed": fl_exec / (ms * 1e-3) / 1e12,
+                                    "frac_of_78.6TF_f64_matrix_peak": fl_exec / (ms * 1e-3) / 1e12 / 78.6,
+                                    "bytes_read_algorithmic": bl, "GBs": bl / (ms * 1e-3) / 1e9,
+                                    "note": "[X y]'[X y] with v_mfma_f64_16x16x4_f64, upper-triangle "
+                                            "16x16 tiles only (mirrored by the reduce kernel); time = "
+                                            "gram_mfma_kernel + gram_reduce_kernel"}
             del outl, Xl, yl
             cl.close()
     except Exception as e:
