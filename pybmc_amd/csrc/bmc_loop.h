@@ -598,31 +598,56 @@ __device__ __forceinline__ void panel_rss_multi(const T* __restrict__ xp, const 
 #pragma unroll
         for (int c = 0; c < CPP; ++c) { a0[c][v] = yv; a1[c][v] = 0.0; }
     }
+    // Whole blocks of 16 columns take u through DPP row broadcasts (see fmac_rowbcast_neg): one
+    // ds_read_b64 per chain and block loads u[c][j .. j+15] spread over the lanes of every row,
+    // instead of one LDS broadcast read per (chain, column) -- with 8 chains those reads, 2 LDS
+    // cycles per double and wave, were what bound the pass (C5 x 8 chains: 2048 per panel and
+    // wave = 13.6 us of LDS pipe per iteration and CU beside 16 us of memory time).  Operands
+    // and per-chain operation order are those of the column loop below, bit for bit.
+    const int lane = threadIdx.x & 63;
     int j = 0;
-    for (; j + UN <= K; j += UN) {
-        T x[UN][VEC];
+    for (; j + 16 <= K; j += 16) {
+        double urow[CPP];
 #pragma unroll
-        for (int q = 0; q < UN; ++q)
+        for (int c = 0; c < CPP; ++c) urow[c] = u[c * kpad + j + (lane & 15)];
+        // (the values are pinned where they are loaded: the DPP statements are opaque to hipcc,
+        // which otherwise re-reads u from LDS in front of every one of them and sinks each
+        // column's global load, with a full vmcnt(0) wait, next to its first use)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                x[q][v] = NT ? __builtin_nontemporal_load(&xp[(size_t)(j + q) * RP + v])
-                             : xp[(size_t)(j + q) * RP + v];
+        for (int c = 0; c < CPP; ++c) asm volatile("" : "+v"(urow[c]));
+        static_for<16 / UN>([&](auto bc) {
+            constexpr int B = decltype(bc)::value;
+            T x[UN][VEC];
 #pragma unroll
-        for (int q = 0; q < UN; q += 2)
+            for (int q = 0; q < UN; ++q)
 #pragma unroll
-            for (int c = 0; c < CPP; ++c) {
-                const double u0 = u[c * kpad + j + q], u1 = u[c * kpad + j + q + 1];
+                for (int v = 0; v < VEC; ++v)
+                    x[q][v] = NT ? __builtin_nontemporal_load(&xp[(size_t)(j + B * UN + q) * RP + v])
+                                 : xp[(size_t)(j + B * UN + q) * RP + v];
+#pragma unroll
+            for (int q = 0; q < UN; ++q)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) asm volatile("" : "+v"(x[q][v]));
+            static_for<UN>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                constexpr int NL = B * UN + Q;          // column within the block = lane of its row
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    a0[c][v] = fma(-(double)x[q][v], u0, a0[c][v]);
-                    a1[c][v] = fma(-(double)x[q + 1][v], u1, a1[c][v]);
+                    const double xd = (double)x[Q][v];
+#pragma unroll
+                    for (int c = 0; c < CPP; ++c)
+                        fmac_rowbcast_neg<NL, (NL == 0)>((Q & 1) ? a1[c][v] : a0[c][v],
+                                                                   urow[c], xd);
                 }
-            }
+            });
+        });
     }
     for (; j < K; ++j)
 #pragma unroll
         for (int c = 0; c < CPP; ++c) {
             const double u0 = u[c * kpad + j];
+            // (columns past the last whole block of 16 all go to the first chain of sums, as in
+            // the single-chain panel_rss, whose blocks are 16 columns too)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) a0[c][v] = fma(-(double)xp[(size_t)j * RP + v], u0, a0[c][v]);
         }
