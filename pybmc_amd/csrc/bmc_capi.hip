@@ -254,7 +254,7 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
     const size_t es = c->f32 ? 4 : 8;
     const size_t panel_bytes = (size_t)(c->k + 1) * RP * es;
     // u slices for up to 8 chains per pass + partial sums + control words + alignment slack
-    const size_t fixed = (size_t)((c->k + 63) / 64 * 64) * 8 * 8 + 72 * 8 + 64;
+    const size_t fixed = (size_t)((c->k + 63) / 64 * 64) * 8 * 8 + (512 + 8) * 8 + 64;
     const int NP = c->npanels;
     const bmc_tuning& tu = c->tune;
     auto lds_fits = [&](int G) {

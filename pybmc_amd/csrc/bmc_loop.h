@@ -9,6 +9,7 @@
 namespace bmc {
 
 constexpr int MAX_KCH = 4;        // K <= 256 columns (64 per lane-chunk)
+constexpr int RED_DOUBLES = 512;  // LDS doubles of the group-level sum (group_allreduce)
 constexpr int MAX_GROUPS = 256;   // 8 teams of <= 32 groups (exchange_sum)
 constexpr unsigned long long SPIN_TIMEOUT_TICKS = 400000000ull;  // 4 s of s_memrealtime (100 MHz)
 
@@ -26,7 +27,8 @@ __host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bo
     const size_t kp = (size_t)((K + 63) & ~63) * sizeof(double) * (size_t)u_slices;
     size_t o = 0;
     L.u = o;   o += kp;
-    L.red = o; o += 64 * sizeof(double);   // [chains per pass <= 8][waves <= 8]
+    L.red = o; o += RED_DOUBLES * sizeof(double);   // one chain: [waves <= 8][64 lanes]; several
+                                                    // chains per pass: [chains <= 8][waves <= 8]
     L.ctl = o; o += 8 * sizeof(double);
     L.aux = o; o += (size_t)((aux_doubles + 1) & ~1) * sizeof(double);
     L.y = o;
@@ -472,14 +474,15 @@ struct PanelStore {
 // ---- all-reduce of the lane partials over the chain's groups -----------------------------
 // Every wave calls it (it contains the group barrier).  In wave 0 the return value is the
 // chain-wide sum (identical bits in every group); `ok` is false when the spin expired.
-// Other waves get an unspecified value.  Order of summation is fixed: DPP butterfly inside a
-// wave, waves in index order, groups in index order.
+// Other waves get an unspecified value.  Order of summation is fixed: lane by lane over the
+// waves in a fixed tree, a DPP butterfly over the lanes, groups in index order.
 // SINGLE = the chain lives in ONE workgroup (G == 1): nothing to exchange, the group total is
 // the chain total.  A template parameter, not a run-time test, so that the multi-group code is
 // byte-for-byte what it was (a run-time `if (G == 1)` cost the C2 path 4 %).
-// `red` holds 8 per-wave slots; the slots of waves that do not exist stay 0 (zeroed by the
-// caller before the loop).  Lane w < 8 reads slot w and three DPP steps add them in a fixed
-// tree, ((r0+r1)+(r2+r3)) + ((r7+r6)+(r5+r4)): no trip count, one LDS read, 4 VGPRs.
+// sum_wave_slots (several chains per pass, group_allreduce_multi): `red` holds 8 per-wave slots
+// per chain; the slots of waves that do not exist stay 0 (zeroed by the caller before the
+// loop).  Lane w < 8 reads slot w and three DPP steps add them in a fixed tree,
+// ((r0+r1)+(r2+r3)) + ((r7+r6)+(r5+r4)): no trip count, one LDS read, 4 VGPRs.
 __device__ __forceinline__ double sum_wave_slots(const double* red, int lane) {
     double v = lane < 8 ? red[lane] : 0.0;
     v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]
@@ -557,17 +560,37 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     return tot;
 }
 
-template <bool SINGLE = false>
+// LANEWISE (register residency with one row per lane: C2, notebook-sized chains, N = 100 000 x
+// 32): the waves of a group do NOT reduce their lanes first.  Every wave leaves its 64 lane
+// partials in its row of `red` ([8 waves][64 lanes], rows of absent waves stay 0: zeroed by the
+// caller before the loop), and after the barrier wave 0 adds the 8 rows lane by lane in a fixed
+// tree, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), and runs ONE wave-level sum -- instead of a
+// wave_sum per wave in front of the barrier (two of them interleaved on the SIMD that two of a
+// CU's five waves share) and a second, 8-slot one behind it.  Same-box A/B (14 rounds): C2
+// 1.112 -> 1.085 us, N = 629 0.599 -> 0.570, N = 100 000 x 32 2.25 -> 2.02; but C4 (two rows
+// per lane) 3.26 -> 3.41 and C5 (streamed) 15.8 -> 16.1, which therefore keep the other form:
+// a wave_sum per wave, 8 slots, three DPP steps in wave 0.
+template <bool SINGLE = false, bool LANEWISE = false>
 __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
                                                   int wave, int nw, int lane, unsigned epoch,
                                                   bool local, bool& ok STAMP_PARAMS) {
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
+    if constexpr (LANEWISE) {
+        red[wave * 64 + lane] = s;
+    } else {
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+    }
     GSTAMP(3);
     __syncthreads();
     ok = true;
     if (wave != 0) return 0.0;
-    s = sum_wave_slots(red, lane);
+    if constexpr (LANEWISE) {
+        const double r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
+        const double r4 = red[256 + lane], r5 = red[320 + lane], r6 = red[384 + lane], r7 = red[448 + lane];
+        s = wave_sum(((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)));
+    } else {
+        s = sum_wave_slots(red, lane);
+    }
     GSTAMP(4);
     if constexpr (SINGLE) return s;
     return exchange_sum<false>(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS);

@@ -118,7 +118,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
 
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad; j += blockDim.x) u_lds[j] = 0.0;
-    if (tid < 64) red[tid] = 0.0;   // slots of absent waves stay 0 (sum_wave_slots)
+    for (int j = tid; j < RED_DOUBLES; j += blockDim.x) red[j] = 0.0;   // rows / slots of absent waves stay 0
     if (tid == 0) { ctl[0] = a.sigma2_init; ctl[1] = 0.0; ctl[2] = 0.0; ctl[3] = 1.0; }
 
     PanelStore<T, VEC, MODE, KMAX, PPW> store;
@@ -226,7 +226,8 @@ void gibbs_loop_kernel(GibbsArgs a) {
         // as far as the loop header can tell); the exchange hides them here
         if constexpr (!SINGLE) prefetch();
         bool got;
-        const double rss = group_allreduce<SINGLE>(part, red, gr + (size_t)(t & 1) * a.gran_stride,
+        const double rss = group_allreduce<SINGLE, (MODE == MODE_REG && VEC == 1)>(
+            part, red, gr + (size_t)(t & 1) * a.gran_stride,
                                                    G, g, wave, nw, lane, epoch, local, got STAMP_ARGS);
         STAMP(8);
         if (recorder) {
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     double* ctl = reinterpret_cast<double*>(smem + L.ctl);   // [1] abort, [2] local
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad * CPP; j += blockDim.x) u_lds[j] = 0.0;
-    if (tid < 64) red[tid] = 0.0;   // slots of absent waves stay 0 (sum_wave_slots)
+    for (int j = tid; j < RED_DOUBLES; j += blockDim.x) red[j] = 0.0;   // rows / slots of absent waves stay 0
     if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; }
 
     PanelStore<T, VEC, MODE, KMAX, PPW> store;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
 
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad; j += blockDim.x) u_lds[j] = 0.0;
-    if (tid < 64) red[tid] = 0.0;   // slots of absent waves stay 0 (sum_wave_slots)
+    for (int j = tid; j < RED_DOUBLES; j += blockDim.x) red[j] = 0.0;   // rows / slots of absent waves stay 0
     if (a.vt_in_lds)
         for (int e = tid; e < K * Km; e += blockDim.x) vt_lds[e] = a.Vt[e];
     if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; ctl[4] = 0.0; }
@@ -633,7 +634,8 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
             bool stamping = false;
             unsigned long long acc_[12] = {}, last_ = 0;
 #endif
-            const double rss_prop = group_allreduce(part, red, gr + (size_t)(nex & 1) * a.gran_stride,
+            const double rss_prop = group_allreduce<false, (MODE == MODE_REG && VEC == 1)>(
+                part, red, gr + (size_t)(nex & 1) * a.gran_stride,
                                                     G, g, wave, nw, lane, nex + 1, local, got STAMP_ARGS);
             ++nex;
             if (wave == 0) {

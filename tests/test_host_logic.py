@@ -139,3 +139,60 @@ def test_bench_cpu_baseline_leg_runs_on_the_host():
     assert out["kind"] == "port" and out["unit"] == "samples/s" and out["value"] > 0
     assert out["cores"] >= 1 and "iterations" in out["sample"]
     assert out.get("value_1_thread", 1.0) > 0
+
+
+def test_run_on_devices_splits_chains_like_ranks(monkeypatch):
+    """train(devices=[...]) -> chains.run_on_devices: one context and one host thread per
+    device, chains split like ranks split them, blocks concatenated in global chain order, a
+    device listed twice used once.  The contexts are stand-ins (no GPU here)."""
+    import threading
+    from pybmc_amd import _lib, chains
+
+    made, lock = {}, threading.Lock()
+
+    class FakeCtx:
+        def __init__(self, dev):
+            self.dev, self.threads, self.problem, self.prior = dev, set(), None, None
+
+        def set_problem(self, y, X, dtype=None):
+            self.problem = (len(y), X.shape, dtype)
+
+        def set_prior(self, b0, C0, nu0, s20):
+            self.prior = (nu0, s20)
+
+        def gibbs_run(self, n_chains, iters, seeds=None):
+            with lock:
+                self.threads.add(threading.get_ident())
+            out = np.empty((n_chains, iters, 3))
+            for c, s in enumerate(seeds):
+                out[c] = float(s) + 1000.0 * self.dev
+            return out, {"device": self.dev, "n_chains": n_chains}
+
+    def fake_default_context(dev=0):
+        with lock:
+            return made.setdefault(dev, FakeCtx(dev))
+
+    monkeypatch.setattr(_lib, "default_context", fake_default_context)
+    y, X = np.zeros(10), np.zeros((10, 2))
+    prior = (np.zeros(2), np.eye(2), 1.0, 0.02)
+    seeds = np.arange(1, 8, dtype=np.uint64)
+    out, stats = chains.run_on_devices(y, X, 5, prior, 7, seeds, [0, 1, 1, 2], dtype=np.float32)
+    assert out.shape == (7, 5, 3) and sorted(made) == [0, 1, 2]
+    # chain_block(7, 3, r): [0,1,2], [3,4], [5,6] -> devices 0, 1, 2
+    want_dev = [0, 0, 0, 1, 1, 2, 2]
+    assert np.array_equal(out[:, 0, 0], seeds.astype(float) + 1000.0 * np.array(want_dev))
+    assert [s["n_chains"] for s in stats] == [3, 2, 2]
+    assert all(c.problem == (10, (10, 2), np.float32) and c.prior == (1.0, 0.02) for c in made.values())
+    main = threading.get_ident()                 # each context driven by one worker thread
+    assert all(len(c.threads) == 1 and main not in c.threads for c in made.values())
+    one, _ = chains.run_on_devices(y, X, 5, prior, 1, [9], [2])
+    assert one.shape == (5, 3) and one[0, 0] == 9.0 + 2000.0
+    with pytest.raises(ValueError):
+        chains.run_on_devices(y, X, 5, prior, 2, [1, 2], [])
+
+    class Boom(FakeCtx):
+        def gibbs_run(self, *a, **k):
+            raise np.linalg.LinAlgError("Singular matrix")
+    made[1] = Boom(1)
+    with pytest.raises(np.linalg.LinAlgError):      # a worker's exception reaches the caller
+        chains.run_on_devices(y, X, 5, prior, 7, seeds, [0, 1, 2])
