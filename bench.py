@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--rank-timeout-s", type=float, default=1500.0,
                     help="self-spawned ranks are stopped after this long")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even for one rank, so that the "
+                         "collective leg runs on a one-GPU box")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="rehearse the launch / rendezvous / pooling plumbing on the CPU with "
                          "gloo and a stand-in for the sampler; measures nothing")
@@ -226,8 +229,10 @@ def rank_main(args):
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if dry:
             dist.init_process_group(backend, rank=rank, world_size=world)
         else:
@@ -262,7 +267,7 @@ def rank_main(args):
     def step(record):
         st = ctx.gibbs_run_device(len(mine), T, seeds, out.data_ptr())
         pooled = out
-        if world > 1:
+        if use_dist:
             t_g = time.perf_counter()
             pooled = pool_samples(out, n_chains)   # returns once the collective has read `out`
             sync()
@@ -275,17 +280,17 @@ def rank_main(args):
 
     for _ in range(args.warmup):
         st, pooled = step(False)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st, pooled = step(True)
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -295,7 +300,7 @@ def rank_main(args):
                  "loop_ms": float(np.mean(loop_ms)) if loop_ms else 0.0,
                  "allgather_ms": float(np.mean(gather_ms)) if gather_ms else 0.0}
     infos = [mine_info]
-    if world > 1:
+    if use_dist:
         infos = [None] * world
         dist.all_gather_object(infos, mine_info)
 
@@ -332,8 +337,8 @@ def rank_main(args):
         if dry:
             line["dry_run"] = True
         line["rccl"] = {
-            "world": dist.get_world_size() if world > 1 else 1,
-            "backend": (dist.get_backend() if world > 1 else "none (single rank: no collective)"),
+            "world": dist.get_world_size() if use_dist else 1,
+            "backend": (dist.get_backend() if use_dist else "none (single rank: no collective)"),
             "devices": [i["device"] for i in infos],
             "allgather_bytes_per_rank": len(mine) * T * (K + 1) * 8,
             "allgather_ms": max(i["allgather_ms"] for i in infos),
@@ -350,7 +355,7 @@ def rank_main(args):
                 line["cpu_baseline"] = cb
                 line["gpu_over_cpu_best"] = value / cb["best_value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -34,3 +34,24 @@ def test_one_hip_runtime_in_the_process():
     with open("/proc/self/maps") as f:
         libs = {line.split()[-1] for line in f if "libamdhip64" in line}
     assert len(libs) == 1, libs
+
+
+def test_bench_rccl_leg_with_one_rank():
+    """The RCCL leg of bench.py (init, barrier, all_gather_into_tensor on the sampler's output
+    block, all_reduce of the time, all_gather_object, destroy) executed with backend "nccl" on
+    this box's one GPU: a world of one rank (--force-dist).  More ranks need more GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist",
+                        "--steps", "2", "--warmup", "1", "--iters", "3000", "--no-extra",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl"]["backend"] == "nccl" and line["rccl"]["world"] == 1
+    assert line["rccl"]["allgather_ms"] > 0 and line["rccl"]["allgather_bytes_per_rank"] == 3000 * 33 * 8
+    assert line["value"] > 1e5 and line["n_gpus"] == 1 and line["roofline"]["bound"] == "latency"
