@@ -519,7 +519,12 @@ struct NoIdleWork {
 // area (pair 264 + team), which the other members poll.  One more local hop, but 8 agent-scope
 // pollers per chain instead of G: with 8 chains per pass the agent-scope polls of 8 x 196 waves
 // made the second level 3.5x slower than it is for one chain (stamps, dev_stamps_multi.py).
-template <bool RELAY = false, typename F = NoIdleWork>
+// TEAMS / LOCAL: -1 = decided at run time (G > 32; the `local` argument), 0 / 1 = known to the
+// caller at compile time.  The register-resident loop kernel is instantiated for chains of at
+// most 32 groups and runs one of two copies of its loop, chosen once after the placement check:
+// with both run-time tests and the dead two-level code out of the loop an iteration at C2 is
+// 3 % shorter (1.090 -> 1.059 us, same-box A/B).
+template <bool RELAY = false, typename F = NoIdleWork, int TEAMS = -1, int LOCAL = -1>
 __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g, int lane,
                                                unsigned epoch, bool local, bool& ok STAMP_PARAMS,
                                                F idle = F()) {
@@ -529,7 +534,8 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     size_t opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
     gp += opaque0;
-    const bool teams = G > 32;
+    const bool teams = TEAMS < 0 ? G > 32 : TEAMS != 0;
+    if constexpr (LOCAL >= 0) local = LOCAL != 0;
     const int team = teams ? (g & 7) : 0, rank = teams ? (g >> 3) : g;
     const int members = teams ? ((G - team + 7) >> 3) : G;
     gu64* gp1 = gp + gran_at(64 * team);
@@ -570,7 +576,7 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
 // 1.112 -> 1.085 us, N = 629 0.599 -> 0.570, N = 100 000 x 32 2.25 -> 2.02; but C4 (two rows
 // per lane) 3.26 -> 3.41 and C5 (streamed) 15.8 -> 16.1, which therefore keep the other form:
 // a wave_sum per wave, 8 slots, three DPP steps in wave 0.
-template <bool SINGLE = false, bool LANEWISE = false>
+template <bool SINGLE = false, bool LANEWISE = false, int TEAMS = -1, int LOCAL = -1>
 __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
                                                   int wave, int nw, int lane, unsigned epoch,
                                                   bool local, bool& ok STAMP_PARAMS) {
@@ -593,7 +599,7 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
     }
     GSTAMP(4);
     if constexpr (SINGLE) return s;
-    return exchange_sum<false>(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS);
+    return exchange_sum<false, NoIdleWork, TEAMS, LOCAL>(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS);
 }
 
 // ---- several chains per pass (streaming / LDS residency) ---------------------------------

@@ -92,7 +92,10 @@ constexpr bool loop_can_pack() {
            !(sizeof(T) == 4 && KMAX == 64);   // (f32, 64 columns spills at 128)
 }
 
-template <typename T, int VEC, int MODE, int KMAX, int PPW, bool SINGLE = false, bool PACK = false>
+// SMALLG: the host promises G <= 32 (one-level exchange); the loop then exists in two copies,
+// one per exchange scope, chosen once after the placement check (exchange_sum, TEAMS / LOCAL).
+template <typename T, int VEC, int MODE, int KMAX, int PPW, bool SINGLE = false, bool PACK = false,
+          bool SMALLG = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(1, 512), amdgpu_waves_per_eu(PACK ? 4 : 2)))
 void gibbs_loop_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
@@ -169,6 +172,8 @@ void gibbs_loop_kernel(GibbsArgs a) {
     unsigned long long acc_[12] = {}, last_ = 0;
     if (stamping) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
+    auto run_loop = [&](auto scope_c) {
+    constexpr int LOCALK = decltype(scope_c)::value;     // -1: `local` tested where it is used
     for (int64_t t = 0; t < T_it; ++t) {
         const unsigned epoch = (unsigned)(t + 1);
         STAMP(7);
@@ -226,7 +231,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
         // as far as the loop header can tell); the exchange hides them here
         if constexpr (!SINGLE) prefetch();
         bool got;
-        const double rss = group_allreduce<SINGLE, (MODE == MODE_REG && VEC == 1)>(
+        const double rss = group_allreduce<SINGLE, (MODE == MODE_REG && VEC == 1), (SMALLG ? 0 : -1), LOCALK>(
             part, red, gr + (size_t)(t & 1) * a.gran_stride,
                                                    G, g, wave, nw, lane, epoch, local, got STAMP_ARGS);
         STAMP(8);
@@ -253,6 +258,13 @@ void gibbs_loop_kernel(GibbsArgs a) {
             }
             STAMP(6);
         }
+    }
+    };   // run_loop
+    if constexpr (SMALLG) {
+        if (local) run_loop(std::integral_constant<int, 1>{});
+        else run_loop(std::integral_constant<int, 0>{});
+    } else {
+        run_loop(std::integral_constant<int, -1>{});
     }
 #ifdef BMC_STAMPS
     if (stamping && lane == 0)
@@ -719,7 +731,7 @@ static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
         if constexpr (loop_can_pack<T, VEC, MODE, KMAX, PPW>()) {
             hipFuncAttributes at;
             const hipError_t e = hipFuncGetAttributes(
-                &at, (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>);
+                &at, (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true, true>);
             if (e != hipSuccess) return e;
             *a.query_regs = at.numRegs;
         }
@@ -727,14 +739,19 @@ static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
     }
     const dim3 grid(a.nslot * a.G), block(64 * a.waves);
     if constexpr (loop_can_pack<T, VEC, MODE, KMAX, PPW>()) {
-        if (a.pack && a.G > 1)
-            return launch_or_query((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true>,
-                                   grid, block, lds, s, a, a.query_occupancy);
+        if (a.pack && a.G > 1)   // (two chains per XCD implies G <= 32)
+            return launch_or_query(
+                (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, true, true>, grid, block,
+                lds, s, a, a.query_occupancy);
     }
     if constexpr (MODE == MODE_REG) {
         if (a.G == 1)   // the chain fits one workgroup: no exchange code at all
             return launch_or_query((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, true>,
                                    grid, block, lds, s, a, a.query_occupancy);
+        if (a.G <= 32)  // one-level exchange, known at compile time (SMALLG)
+            return launch_or_query(
+                (const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW, false, false, true>, grid, block,
+                lds, s, a, a.query_occupancy);
     }
     return launch_or_query((const void*)gibbs_loop_kernel<T, VEC, MODE, KMAX, PPW>, grid, block,
                            lds, s, a, a.query_occupancy);
