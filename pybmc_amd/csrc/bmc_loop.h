@@ -576,7 +576,7 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
 // 1.112 -> 1.085 us, N = 629 0.599 -> 0.570, N = 100 000 x 32 2.25 -> 2.02; but C4 (two rows
 // per lane) 3.26 -> 3.41 and C5 (streamed) 15.8 -> 16.1, which therefore keep the other form:
 // a wave_sum per wave, 8 slots, three DPP steps in wave 0.
-template <bool SINGLE = false, bool LANEWISE = false, int TEAMS = -1, int LOCAL = -1>
+template <bool SINGLE = false, bool LANEWISE = false, int TEAMS = -1, int LOCAL = -1, int ROLE = -1>
 __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
                                                   int wave, int nw, int lane, unsigned epoch,
                                                   bool local, bool& ok STAMP_PARAMS) {
@@ -589,7 +589,7 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
     GSTAMP(3);
     __syncthreads();
     ok = true;
-    if (wave != 0) return 0.0;
+    if (ROLE < 0 ? wave != 0 : ROLE != 0) return 0.0;   // (ROLE: the caller knows its wave's role)
     if constexpr (LANEWISE) {
         const double r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
         const double r4 = red[256 + lane], r5 = red[320 + lane], r6 = red[384 + lane], r7 = red[448 + lane];

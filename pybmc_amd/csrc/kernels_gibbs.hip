@@ -172,12 +172,21 @@ void gibbs_loop_kernel(GibbsArgs a) {
     unsigned long long acc_[12] = {}, last_ = 0;
     if (stamping) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
-    auto run_loop = [&](auto scope_c) {
+    // One iteration loop, instantiated per (exchange scope, role, recording duty).  ROLE: 0 =
+    // the leader wave (wave 0), 1 = a worker wave, -1 = tested at run time; REC likewise for the
+    // recording duty of group 0's last wave.  The chains of at most 32 groups (SMALLG) run
+    // role-specific copies -- every wave executes the same two barriers per iteration and leaves
+    // the loop at the same place, so the copies stay in step -- which takes the leader's and
+    // the recorder's tests out of each other's loops.
+    auto run_loop = [&](auto scope_c, auto role_c, auto rec_c) {
     constexpr int LOCALK = decltype(scope_c)::value;     // -1: `local` tested where it is used
+    constexpr int ROLE = decltype(role_c)::value, REC = decltype(rec_c)::value;
+    const bool is_leader = ROLE < 0 ? wave == 0 : ROLE == 0;
+    const bool is_rec = REC < 0 ? recorder : REC == 1;
     for (int64_t t = 0; t < T_it; ++t) {
         const unsigned epoch = (unsigned)(t + 1);
         STAMP(7);
-        if (wave == 0) {
+        if (is_leader) {
 #pragma unroll
             for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
@@ -197,7 +206,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
         // the residual pass to hide the loads behind, so it issues them here; chains with an
         // exchange issue them behind the pass (below).
         auto prefetch = [&]() {
-            if (wave == 0 && t + 1 < T_it) {
+            if (is_leader && t + 1 < T_it) {
 #pragma unroll
                 for (int ch = 0; ch < KCH; ++ch) {
                     const int j = ch * 64 + lane;
@@ -208,7 +217,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
         };
         if constexpr (SINGLE) prefetch();
         double u_rec[KCH], sp_rec = 0.0, g_rec = 1.0;
-        if (recorder) {  // copy now (wave 0 rewrites u_lds after its gather); store later
+        if (is_rec) {  // copy now (wave 0 rewrites u_lds after its gather); store later
 #pragma unroll
             for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
@@ -231,11 +240,11 @@ void gibbs_loop_kernel(GibbsArgs a) {
         // as far as the loop header can tell); the exchange hides them here
         if constexpr (!SINGLE) prefetch();
         bool got;
-        const double rss = group_allreduce<SINGLE, (MODE == MODE_REG && VEC == 1), (SMALLG ? 0 : -1), LOCALK>(
+        const double rss = group_allreduce<SINGLE, (MODE == MODE_REG && VEC == 1), (SMALLG ? 0 : -1), LOCALK, ROLE>(
             part, red, gr + (size_t)(t & 1) * a.gran_stride,
                                                    G, g, wave, nw, lane, epoch, local, got STAMP_ARGS);
         STAMP(8);
-        if (recorder) {
+        if (is_rec) {
             // row t = [u_t, .]; sigma of the PREVIOUS row (its sp, g were final at B1)
 #pragma unroll
             for (int ch = 0; ch < KCH; ++ch) {
@@ -244,7 +253,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
             }
             if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
         }
-        if (wave == 0) {
+        if (is_leader) {
             if (!got) {
                 if (lane == 0) { ctl[1] = 1.0; a.status[chain] = 1; }
             } else {
@@ -260,11 +269,23 @@ void gibbs_loop_kernel(GibbsArgs a) {
         }
     }
     };   // run_loop
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IR = std::integral_constant<int, -1>;
     if constexpr (SMALLG) {
-        if (local) run_loop(std::integral_constant<int, 1>{});
-        else run_loop(std::integral_constant<int, 0>{});
+        auto by_role = [&](auto scope_c) {
+            if (wave == 0) {
+                if (recorder) run_loop(scope_c, I0{}, I1{});   // (a group of one wave)
+                else run_loop(scope_c, I0{}, I0{});
+            } else {
+                if (recorder) run_loop(scope_c, I1{}, I1{});
+                else run_loop(scope_c, I1{}, I0{});
+            }
+        };
+        if (local) by_role(I1{});
+        else by_role(I0{});
     } else {
-        run_loop(std::integral_constant<int, -1>{});
+        run_loop(IR{}, IR{}, IR{});
     }
 #ifdef BMC_STAMPS
     if (stamping && lane == 0)
