@@ -190,7 +190,10 @@ void gibbs_loop_kernel(GibbsArgs a) {
 #pragma unroll
             for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
-                if (ch * 64 < K && j < K)
+                // register residency (one lane-chunk): every lane draws, no exec-mask region on
+                // the serial path; columns K..63 have lam = c1 = c2 = xi = 0 and draw u = 0 into
+                // the zero padding of u_lds
+                if (MODE == MODE_REG || (ch * 64 < K && j < K))
                     u_lds[j] = draw_u(lam_r[ch], c1_r[ch], c2_r[ch], xi_next[ch], sp_eff, g_eff, sq_sp);
             }
         }
