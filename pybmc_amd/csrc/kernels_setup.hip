@@ -58,212 +58,318 @@ hipError_t launch_panelize(const void* Xsrc, const void* ysrc, int64_t n, int32_
 // =========================================================================
 // Gram with f64 MFMA
 // =========================================================================
-// One workgroup (4 waves) owns a chunk of 64-row sub-panels and up to 32 of the
-// upper-triangular 16x16 tile pairs of G = A'A, A = [X | y | 0-pad] (Ka_pad cols).
-// Each sub-panel is staged once into LDS as f64 [Ka_pad][66] (column-major, row
-// stride 66 doubles -> the MFMA operand reads below are bank-conflict free: a
-// 32-lane half covers 16 columns x 2 rows = banks {4c,4c+1} and {4c+2,4c+3}).
-// MFMA operand maps (cdna guide section 3, f64 form): lane l supplies
-// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D: col = l&15,
-// row = (l>>4) + 4*reg.  For G tile (ti,tj): A[i][k] = a[n0+k][16ti+i],
-// B[k][j] = a[n0+k][16tj+j].
-constexpr int GRAM_LDR = 66;
+// G = A'A, A = [X | y | 0-pad] (Ka_pad columns), as the 16x16 tiles (ti, tj >= ti) of the upper
+// triangle ("tile pairs"); the reduce kernel mirrors.  One workgroup of 8 waves owns a chunk of
+// SR-row sub-panels and ALL tile pairs, so every row of the matrix is read from memory once:
+//   * the sub-panel is staged into LDS as f64 [Ka_pad][SR + 2] (column-major; the row stride of
+//     SR + 2 doubles makes the MFMA operand reads bank-conflict free: a 32-lane half covers 16
+//     columns x 2 rows = banks {4c, 4c+1} and {4c+2, 4c+3}), double-buffered: the next sub-panel
+//     travels global -> registers while the MFMAs of the current one run and is written to the
+//     other buffer behind them -- one barrier per sub-panel;
+//   * wave (ts, rs) of the TS x RS active waves accumulates tile pairs ts*NTW .. ts*NTW+NTW-1
+//     (NTW accumulators of 8 registers, AGPRs) over the k-steps [rs*KPW, (rs+1)*KPW) of every
+//     sub-panel; the loop body is branch-free (slots past the last pair recompute pair 0 and are
+//     never written), so hipcc keeps several LDS reads in flight under the MFMAs.  (The first
+//     version guarded every MFMA with a wave-uniform branch: ds_read, ds_read, s_waitcnt
+//     lgkmcnt(0), v_mfma -- fully serialised, 27 % MFMA busy at C5 -- and re-staged every row
+//     once per group of 64 tile pairs.)
+//   * RS > 1 (few tile pairs: the row dimension is split instead): the RS partial accumulators
+//     of a tile are added in rs order through LDS after the last sub-panel.
+// Wide problems (C5: Ka_pad = 272, 153 pairs): SR = 32 (2 x 74 KB of LDS), NTW = 20, TS = 8.
+// MFMA operand maps (cdna guide section 3, f64 form): lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; D: col = l&15, row = (l>>4) + 4*reg.  For G tile (ti,tj):
+// A[i][k] = a[n0+k][16ti+i], B[k][j] = a[n0+k][16tj+j].
+// The chunk's tiles go to partial[chunk][pair][16 x 16] (only the pairs, compact).
+constexpr int GRAM_THREADS = 512;
+constexpr int GRAM_NVMAX = 9;   // two-row pieces per thread: Ka_pad * SR / 2 / 512 <= 272 * 16 / 512
 
-// Staging: the next sub-panel travels global -> registers while the MFMAs of the current one
-// run (one LDS buffer: at K = 256 a 64-row sub-panel of all 272 columns is 140 KiB), then
-// registers -> LDS between two barriers.  Each thread moves NV two-row pieces (16 B of f64,
-// 8 B of f32): piece e = (column e / 32, rows 2 (e % 32), +1), so 32 consecutive threads read
-// 512 contiguous bytes of one column.  (The first version staged with a scalar loop straight
-// into LDS in front of the MFMAs: 68 dependent-latency loads per thread and sub-panel, nothing
-// overlapped -- 12 % MFMA busy at C5.)
 template <typename T> struct Pair2 { T a, b; };
 
-template <typename T, int TPW, int NV>
-__global__ __launch_bounds__(256) void gram_mfma_kernel(
+// pair id -> (ti, tj), tj >= ti: row-by-row enumeration of the upper triangle
+__host__ __device__ inline void gram_pair(int id, int ntile, int& ti, int& tj) {
+    int a = 0, rowlen = ntile;
+    while (id >= rowlen) { id -= rowlen; ++a; --rowlen; }
+    ti = a;
+    tj = a + id;
+}
+
+template <typename T, int NTW>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_mfma_kernel(
     const T* __restrict__ X, const T* __restrict__ y, int32_t K, int32_t RP, int32_t nsub,
-    int32_t subs_per_chunk, int32_t Ka_pad, int32_t ntile, int32_t npairs,
-    double* __restrict__ partial) {
+    int32_t subs_per_chunk, int32_t Ka_pad, int32_t ntile, int32_t npairs, int32_t SR, int32_t TS,
+    int32_t RS, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* tile = reinterpret_cast<double*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = blockIdx.x;
-    const int pair0 = (blockIdx.y * 4 + wave) * TPW;
+    const int LDR = SR + 2;
+    const int bufbytes = Ka_pad * LDR * 8;
+    const bool active = wave < TS * RS;
+    const int ts = active ? wave % TS : 0, rs = active ? wave / TS : 0;
+    const int KPW = (SR >> 2) / RS;         // k-steps of 4 rows per wave and sub-panel (even)
+    constexpr int GB = NTW > 10 ? 2 : NTW % 4 == 0 ? 4 : (NTW % 3 == 0 ? 3 : 2);   // tiles per operand group
+                                                  // (20 accumulators: 160 registers, so small groups;
+                                                  // groups of 4 there: same-box A/B 136.6 vs 137.9 us)
+    constexpr int NG = NTW / GB;
 
-    int ti[TPW], tj[TPW];
+    // byte offsets of the wave's tiles' operand columns (wave-uniform: SGPRs)
+    int aoff[NTW], boff[NTW];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        // pair id -> (ti, tj), tj >= ti, row-by-row enumeration of the upper triangle
-        int id = pair0 + q, a = 0, rowlen = ntile;
+    for (int q = 0; q < NTW; ++q) {
+        int id = ts * NTW + q, ti, tj;
         if (id >= npairs) id = 0;
-        while (id >= rowlen) { id -= rowlen; ++a; --rowlen; }
-        ti[q] = a;
-        tj[q] = a + id;
+        gram_pair(id, ntile, ti, tj);
+        aoff[q] = __builtin_amdgcn_readfirstlane(16 * ti * LDR * 8);
+        boff[q] = __builtin_amdgcn_readfirstlane(16 * tj * LDR * 8);
     }
-    f64x4 acc[TPW];
+    f64x4 acc[NTW];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NTW; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     const int s_begin = chunk * subs_per_chunk;
     int s_end = s_begin + subs_per_chunk;
     if (s_end > nsub) s_end = nsub;
     const int kq = lane >> 4, cl = lane & 15;
-    const int npiece = Ka_pad * 32;
+    const int hsh = SR == 64 ? 5 : 4;       // SR / 2 two-row pieces per column
+    const int npiece = Ka_pad << hsh;
 
-    Pair2<T> stage[NV];
+    // (branch-free: pieces past the matrix -- zero-pad columns, or past the last piece -- read a
+    // valid address of y and are zeroed, so the loads are plain instructions that hipcc can
+    // leave in flight under the MFMAs)
+    Pair2<T> stage[GRAM_NVMAX];
     auto fetch = [&](int s) {
-        const int64_t row0 = (int64_t)s * 64;
+        const int64_t row0 = (int64_t)s * SR;
         const int64_t p = row0 / RP;
         const int32_t r0 = (int32_t)(row0 - p * RP);
+        const T* xrow = X + p * K * RP + r0;
+        const T* yrow = y + row0;
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));   // (piece offsets and masks recomputed here, not kept live)
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + i * 256;
-            const int a = e >> 5, r = (e & 31) * 2;
-            Pair2<T> v{(T)0, (T)0};
-            if (e < npiece) {
-                if (a < K) v = *reinterpret_cast<const Pair2<T>*>(&X[(p * K + a) * RP + r0 + r]);
-                else if (a == K) v = *reinterpret_cast<const Pair2<T>*>(&y[row0 + r]);
-            }
+        for (int i = 0; i < GRAM_NVMAX; ++i) {
+            const int e = t0 + i * GRAM_THREADS;
+            const int a = e >> hsh, r = (e & ((1 << hsh) - 1)) * 2;
+            const T* src = a < K ? xrow + (int64_t)a * RP + r : yrow + r;
+            Pair2<T> v = *reinterpret_cast<const Pair2<T>*>(src);
+            if (a > K) v = Pair2<T>{(T)0, (T)0};
             stage[i] = v;
         }
     };
-    if (s_begin < s_end) fetch(s_begin);
-    for (int s = s_begin; s < s_end; ++s) {
+    auto put = [&](int buf) {
+        double* tile = reinterpret_cast<double*>(smem_raw + (size_t)buf * bufbytes);
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + i * 256;
+        for (int i = 0; i < GRAM_NVMAX; ++i) {
+            const int e = t0 + i * GRAM_THREADS;
             if (e < npiece) {
-                double* d = &tile[(e >> 5) * GRAM_LDR + (e & 31) * 2];
+                double* d = &tile[(e >> hsh) * LDR + (e & ((1 << hsh) - 1)) * 2];
                 d[0] = (double)stage[i].a;
                 d[1] = (double)stage[i].b;
             }
         }
-        __syncthreads();
+    };
+    if (s_begin < s_end) {
+        fetch(s_begin);
+        put(0);
+    }
+    __syncthreads();
+    const int lane_off = (cl * LDR + kq + 4 * rs * KPW) * 8;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
         if (s + 1 < s_end) fetch(s + 1);   // in flight under the MFMAs below
-#pragma unroll 4
-        for (int kk = 0; kk < 16; ++kk) {
-            const int rr = kk * 4 + kq;
+        if (active) {
+            // Operands of the next group of GB tiles are read from LDS while the MFMAs of the
+            // current group run (two register sets, alternating).  Two k-steps per trip (KPW is
+            // even), so the set parity is the same at the top of every trip.  The very last
+            // prefetch of a sub-panel reads past the wave's k-range (inside the LDS allocation,
+            // which is padded for it) and is never used.
+            // (LDS byte addresses as 32-bit integers: a generic pointer through the opaque asm
+            // below would turn the reads into flat loads with full vmcnt/lgkmcnt waits)
+            typedef const __attribute__((address_space(3))) double lds_cd;
+            const unsigned base = lds0 + (unsigned)buf * (unsigned)bufbytes + (unsigned)lane_off;
+            double oa[2][GB], ob[2][GB];
+            auto load_group = [&](int set, int g, unsigned b) {
 #pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-                if (pair0 + q < npairs) {  // wave-uniform
-                    const double a = tile[(16 * ti[q] + cl) * GRAM_LDR + rr];
-                    const double b = tile[(16 * tj[q] + cl) * GRAM_LDR + rr];
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                for (int t = 0; t < GB; ++t) {
+                    oa[set][t] = *reinterpret_cast<lds_cd*>(b + (unsigned)aoff[g * GB + t]);
+                    ob[set][t] = *reinterpret_cast<lds_cd*>(b + (unsigned)boff[g * GB + t]);
+                }
+            };
+            load_group(0, 0, base);
+            for (int i = 0; i < KPW; i += 2) {
+                // (running vector addresses of the two k-steps and of the next trip's first: kept
+                // opaque, or hipcc folds the k offsets into 2*NTW more scalar offsets and spills)
+                unsigned bk[3] = {base + i * 32, base + i * 32 + 32, base + i * 32 + 64};
+                asm volatile("" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bk[2]));
+#pragma unroll
+                for (int m = 0; m < 2 * NG; ++m) {
+                    const int mn = m + 1;
+                    load_group(mn & 1, mn % NG, bk[mn / NG]);
+#pragma unroll
+                    for (int t = 0; t < GB; ++t) {
+                        const int q = (m % NG) * GB + t;
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[m & 1][t], ob[m & 1][t], acc[q], 0, 0, 0);
+                    }
+                    // nothing crosses: reads of group m+1, then the MFMAs of group m (left to
+                    // itself hipcc hoists the reads of the whole trip and runs out of registers)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        if (s + 1 < s_end) put(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
-    double* out = partial + (size_t)chunk * Ka_pad * Ka_pad;
+    // the RS row-parts of a tile, added in rs order (both LDS buffers are free now)
+    if (RS > 1) {
+        double* xch = reinterpret_cast<double*>(smem_raw);
+        for (int r = 1; r < RS; ++r) {
+            if (active && rs == r) {
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        if (pair0 + q < npairs) {
+                for (int q = 0; q < NTW; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 16 * ti[q] + kq + 4 * i;
-                const int col = 16 * tj[q] + cl;
-                out[(size_t)row * Ka_pad + col] = acc[q][i];
+                    for (int i = 0; i < 4; ++i) xch[((ts * NTW + q) * 4 + i) * 64 + lane] = acc[q][i];
+            }
+            __syncthreads();
+            if (active && rs == 0) {
+#pragma unroll
+                for (int q = 0; q < NTW; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[q][i] += xch[((ts * NTW + q) * 4 + i) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (active && rs == 0) {
+        double* out = partial + (size_t)chunk * npairs * 256;
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            const int id = ts * NTW + q;
+            if (id < npairs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[(size_t)id * 256 + (kq + 4 * i) * 16 + cl] = acc[q][i];
             }
         }
     }
 }
 
-// Sum the chunk partials (bit-reproducible: fixed order), mirror to the lower triangle.  Four
-// threads per element each sum a quarter of the chunks in chunk order, then
-// (q0 + q1) + (q2 + q3): a dependent chain of nchunk / 4 additions instead of nchunk.
+// Sum the chunk partials (bit-reproducible: fixed order), mirror to the lower triangle.  A
+// workgroup of 4 waves owns 16 consecutive elements of a tile; the chunks are cut into 16 runs:
+// thread (wave w, lane 4 e + q) adds run 4 w + q of element e in chunk order (128 contiguous
+// bytes per run and load instruction), the four runs of a wave meet through two shuffles,
+// (q0 + q1) + (q2 + q3), the four waves through LDS, (w0 + w1) + (w2 + w3): dependent chains of
+// nchunk / 16 additions, 16 x the loads in flight of one thread per element.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial,
-                                                          int32_t nchunk, int32_t Ka,
-                                                          int32_t Ka_pad,
+                                                          int32_t nchunk, int32_t npairs,
+                                                          int32_t ntile, int32_t Ka,
                                                           double* __restrict__ out) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = gid >> 2, part = gid & 3;
-    const bool live = e < Ka * Ka;
-    const int i = live ? e / Ka : 0, j = live ? e % Ka : 0;
-    const int per = (nchunk + 3) / 4;
+    __shared__ double wsum[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 16 + (lane >> 2), part = wave * 4 + (lane & 3);
+    const bool in = e < npairs * 256;
+    int ti = 0, tj = 0;
+    gram_pair(in ? e >> 8 : 0, ntile, ti, tj);
+    const int r = (e >> 4) & 15, c = e & 15;
+    const int i = 16 * ti + r, j = 16 * tj + c;
+    const bool live = in && i < Ka && j < Ka && (ti != tj || r <= c);
+    const int per = (nchunk + 15) / 16;
     const int c0 = part * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
     double s = 0.0;
-    if (live && i <= j)
-        for (int c = c0; c < c1; ++c)
-            s += partial[(size_t)c * Ka_pad * Ka_pad + (size_t)i * Ka_pad + j];
+    if (live)
+        for (int ch = c0; ch < c1; ++ch) s += partial[((size_t)ch * npairs) * 256 + e];
     const double s01 = s + __shfl_xor(s, 1);       // lanes 0,1 -> q0 + q1; lanes 2,3 -> q2 + q3
-    const double lo = __shfl(s01, (threadIdx.x & 60), 64), hi = __shfl(s01, (threadIdx.x & 60) + 2, 64);
-    if (live && i <= j && part == 0) {
-        const double t = lo + hi;
+    const double lo = __shfl(s01, (lane & 60), 64), hi = __shfl(s01, (lane & 60) + 2, 64);
+    if ((lane & 3) == 0) wsum[wave][lane >> 2] = lo + hi;
+    __syncthreads();
+    if (wave == 0 && (lane & 3) == 0 && live) {
+        const int q = lane >> 2;
+        const double t = (wsum[0][q] + wsum[1][q]) + (wsum[2][q] + wsum[3][q]);
         out[(size_t)i * Ka + j] = t;
         out[(size_t)j * Ka + i] = t;
     }
 }
 
-// tile pairs per wave: 8, or 16 for wide problems (fewer workgroups re-stage the same rows)
-static int gram_tpw(int npairs) { return npairs > 64 ? 16 : 8; }
+struct GramGeo {
+    int Ka_pad, ntile, npairs, SR, nsub, spc, nchunk, NTW, TS, RS;
+    size_t lds;
+};
 
-static void gram_geometry(const Panels& P, int& Ka_pad, int& ntile, int& npairs, int& nsub,
-                          int& nchunk, int& spc) {
-    Ka_pad = ((P.k + 1 + 15) / 16) * 16;
-    ntile = Ka_pad / 16;
-    npairs = ntile * (ntile + 1) / 2;
-    nsub = P.npanels * P.vec;  // 64-row sub-panels
-    // sub-panels per chunk: the workgroups (chunks x pair groups) run in rounds of one per CU;
-    // take the chunking whose rounds x sub-panels-per-chunk is least (few, full rounds), with
-    // enough chunks to fill the chip and the partial slabs below ~256 MB
-    const int pgroups = (npairs + 4 * gram_tpw(npairs) - 1) / (4 * gram_tpw(npairs));
-    const size_t per = (size_t)Ka_pad * Ka_pad * 8;
-    long best_cost = -1;
-    spc = 1;
-    for (int c = 1; c <= 64; ++c) {
-        const long chunks = (nsub + c - 1) / c;
-        if (per * (size_t)chunks > ((size_t)256 << 20) && c < 64) continue;
-        const long rounds = (chunks * pgroups + 255) / 256;
-        const long cost = rounds * c;
-        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; spc = c; }   // ties: fewer slabs
-        if (chunks * pgroups <= 256) break;   // one round already: larger chunks only idle CUs
+static GramGeo gram_geometry(const Panels& P) {
+    GramGeo g;
+    g.Ka_pad = ((P.k + 1 + 15) / 16) * 16;
+    g.ntile = g.Ka_pad / 16;
+    g.npairs = g.ntile * (g.ntile + 1) / 2;
+    // 64-row sub-panels while two of them fit the 160 KiB of LDS, else 32 rows
+    g.SR = (size_t)2 * g.Ka_pad * 66 * 8 <= (size_t)160 * 1024 ? 64 : 32;
+    g.nsub = P.npanels * P.vec * (64 / g.SR);
+    // accumulators per wave / tile sets / row parts: the 8 waves as busy as they can be
+    const int opts[4] = {20, 10, 8, 6};
+    double best = -1.0;
+    g.NTW = 20; g.TS = 8; g.RS = 1;
+    for (int o = 0; o < 4; ++o) {
+        const int ntw = opts[o], ts = (g.npairs + ntw - 1) / ntw;
+        if (ts > 8) continue;
+        int rs = 1;
+        while (rs * 2 * ts <= 8 && rs * 2 <= g.SR / 8) rs *= 2;   // (k-steps per wave stay even)
+        // the cross-wave sum of RS > 1 needs ts * ntw tiles of 2 KiB in LDS
+        while (rs > 1 && (size_t)ts * ntw * 2048 > (size_t)160 * 1024) rs /= 2;
+        const double eff = (double)g.npairs / (ts * ntw) * (ts * rs) / 8.0;
+        if (eff > best + 1e-9) { best = eff; g.NTW = ntw; g.TS = ts; g.RS = rs; }
     }
-    nchunk = (nsub + spc - 1) / spc;
+    g.lds = (size_t)2 * g.Ka_pad * (g.SR + 2) * 8 + 64;   // (+ pad: the kernel's last prefetch)
+    if (g.RS > 1 && (size_t)g.TS * g.NTW * 2048 > g.lds) g.lds = (size_t)g.TS * g.NTW * 2048;
+    // sub-panels per chunk: the workgroups run in rounds of one per CU; take the chunking whose
+    // rounds x sub-panels-per-chunk is least (few, full rounds), with enough chunks to fill the chip
+    long best_cost = -1;
+    g.spc = 1;
+    for (int c = 1; c <= 256; ++c) {
+        const long chunks = (g.nsub + c - 1) / c;
+        const long rounds = (chunks + 255) / 256;
+        const long cost = rounds * c;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; g.spc = c; }   // ties: fewer slabs
+        if (chunks <= 256) break;   // one round already: larger chunks only idle CUs
+    }
+    g.nchunk = (g.nsub + g.spc - 1) / g.spc;
+    return g;
 }
 
 size_t gram_scratch_bytes(const Panels& P) {
-    int Ka_pad, ntile, npairs, nsub, nchunk, spc;
-    gram_geometry(P, Ka_pad, ntile, npairs, nsub, nchunk, spc);
-    return (size_t)nchunk * Ka_pad * Ka_pad * sizeof(double);
+    const GramGeo g = gram_geometry(P);
+    return (size_t)g.nchunk * g.npairs * 256 * sizeof(double);
 }
 
-template <typename T, int TPW, int NV>
-static hipError_t launch_gram_t(const Panels& P, dim3 grid, size_t lds, int nsub, int spc, int Ka_pad,
-                                int ntile, int npairs, void* scratch, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute((const void*)gram_mfma_kernel<T, TPW, NV>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <typename T, int NTW>
+static hipError_t launch_gram_t(const Panels& P, const GramGeo& g, void* scratch, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void*)gram_mfma_kernel<T, NTW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gram_mfma_kernel<T, TPW, NV>), grid, dim3(256), lds, s, (const T*)P.X,
-                       (const T*)P.y, P.k, 64 * P.vec, nsub, spc, Ka_pad, ntile, npairs,
-                       (double*)scratch);
+    hipLaunchKernelGGL((gram_mfma_kernel<T, NTW>), dim3(g.nchunk), dim3(GRAM_THREADS), g.lds, s,
+                       (const T*)P.X, (const T*)P.y, P.k, 64 * P.vec, g.nsub, g.spc, g.Ka_pad, g.ntile,
+                       g.npairs, g.SR, g.TS, g.RS, (double*)scratch);
     return hipGetLastError();
 }
 
 template <typename T>
-static hipError_t launch_gram_k(const Panels& P, dim3 grid, size_t lds, int nsub, int spc, int Ka_pad,
-                                int ntile, int npairs, int tpw, void* scratch, hipStream_t s) {
-    // NV = two-row pieces per thread: Ka_pad * 32 / 256
-    if (Ka_pad <= 48) return launch_gram_t<T, 8, 6>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
-    if (Ka_pad <= 128 && tpw == 8)
-        return launch_gram_t<T, 8, 16>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
-    if (tpw == 8) return launch_gram_t<T, 8, 34>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
-    return launch_gram_t<T, 16, 34>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, scratch, s);
+static hipError_t launch_gram_k(const Panels& P, const GramGeo& g, void* scratch, hipStream_t s) {
+    switch (g.NTW) {
+        case 6: return launch_gram_t<T, 6>(P, g, scratch, s);
+        case 8: return launch_gram_t<T, 8>(P, g, scratch, s);
+        case 10: return launch_gram_t<T, 10>(P, g, scratch, s);
+        default: return launch_gram_t<T, 20>(P, g, scratch, s);
+    }
 }
 
 hipError_t launch_gram(const Panels& P, void* scratch, double* gram_out, hipStream_t s) {
-    int Ka_pad, ntile, npairs, nsub, nchunk, spc;
-    gram_geometry(P, Ka_pad, ntile, npairs, nsub, nchunk, spc);
-    if (Ka_pad > 272) return hipErrorInvalidValue;
-    const int tpw = gram_tpw(npairs);
-    const int pgroups = (npairs + 4 * tpw - 1) / (4 * tpw);
-    const size_t lds = (size_t)Ka_pad * GRAM_LDR * sizeof(double);
-    const dim3 grid(nchunk, pgroups);
-    hipError_t e = P.f32 ? launch_gram_k<float>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, tpw, scratch, s)
-                         : launch_gram_k<double>(P, grid, lds, nsub, spc, Ka_pad, ntile, npairs, tpw, scratch, s);
+    const GramGeo g = gram_geometry(P);
+    if (g.Ka_pad > 272 || (size_t)g.Ka_pad * (g.SR / 2) > (size_t)GRAM_NVMAX * GRAM_THREADS)
+        return hipErrorInvalidValue;
+    hipError_t e = P.f32 ? launch_gram_k<float>(P, g, scratch, s) : launch_gram_k<double>(P, g, scratch, s);
     if (e != hipSuccess) return e;
     const int Ka = P.k + 1;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((4 * Ka * Ka + 255) / 256), dim3(256), 0, s,
-                       (const double*)scratch, nchunk, Ka, Ka_pad, gram_out);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(g.npairs * 16), dim3(256), 0, s,
+                       (const double*)scratch, g.nchunk, g.npairs, g.ntile, Ka, gram_out);
     return hipGetLastError();
 }
 
