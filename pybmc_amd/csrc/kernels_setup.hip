@@ -525,7 +525,15 @@ template <typename T, int VEC, int NB, bool NT>
 __device__ __forceinline__ void rss_panel_columns(const T* __restrict__ xp, const double* cf, int K,
                                                   double (&acc)[NB][VEC]) {
     constexpr int RP = 64 * VEC;
-#pragma unroll 8
+    // columns (= coalesced reads of 64 * VEC * sizeof(T) bytes) in flight per wave: 8 KiB worth,
+    // i.e. 8 of the 1 KiB reads, 16 of the 512-byte ones (C4: f32, two rows per lane; C5: f64,
+    // one row per lane) -- with only ~6 waves per CU the depth has to come from each wave
+#ifndef BMC_RSS_INFLIGHT_BYTES
+#define BMC_RSS_INFLIGHT_BYTES 8192
+#endif
+    constexpr int UN_ = BMC_RSS_INFLIGHT_BYTES / (RP * (int)sizeof(T));
+    constexpr int UN = UN_ < 8 ? 8 : UN_ > 32 ? 32 : UN_;
+#pragma unroll UN
     for (int j = 0; j < K; ++j) {
         T xv[VEC];
 #pragma unroll

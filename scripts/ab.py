@@ -6,7 +6,7 @@
 Builds come from `make -C pybmc_amd/csrc variant NAME=x EXTRA="-D..."` (-> .ab/lib_x.so); the
 product library is pybmc_amd/libpybmc_amd.so.  Each round times every build once, in turn;
 the table gives median and min of the loop kernel's HIP-event time per iteration (us).
-Cases: c2 c2x8 c2x16 c4 c4x8 c5 c5x8 hbm hbmx8 n100k n100kx8 small small300 simplex
+Cases: c2 c2x8 c2x16 c4 c4x8 c5 c5x8 hbm hbmx8 n100k n100kx8 small small300 gram_c2/c4/c5 rss_c2/c4/c5/hbm
 """
 import argparse
 import os
@@ -47,6 +47,11 @@ CASES = {   # name: (problem factory, dtype, chains, iterations)
     "gram_c4": (lambda: dense(200000, 64, np.float32), np.float32, 0, 20),
     "gram_c5": (lambda: dense(50000, 256, np.float64), np.float64, 0, 20),
     "small300": (lambda: synth(629, 3), np.float64, 300, 20000),
+    # chains = -1: time the stand-alone residual kernel (one coefficient vector), us per pass
+    "rss_c4": (lambda: dense(200000, 64, np.float32), np.float32, -1, 200),
+    "rss_c5": (lambda: dense(50000, 256, np.float64), np.float64, -1, 100),
+    "rss_hbm": (lambda: dense(2000000, 64, np.float32), np.float32, -1, 30),
+    "rss_c2": (lambda: synth(10000, 32), np.float64, -1, 200),
 }
 
 
@@ -77,7 +82,7 @@ def main():
             c.set_prior(*prior)
             if args.groups or args.waves:
                 c.set_tuning(args.groups, args.waves)
-            if chains:
+            if chains > 0:
                 c.gibbs_run(chains, max(50, iters // 20), seeds=np.arange(chains) + 1)   # warm
             ctxs.append((name, c))
         times = {name: [] for name, _ in ctxs}
@@ -86,8 +91,9 @@ def main():
             # rotate the order: the first build timed after a pause gets a slightly higher clock
             order = ctxs[r % len(ctxs):] + ctxs[:r % len(ctxs)]
             for name, c in order:
-                if not chains:
-                    times[name].append(c.gram_bench(reps=iters) * 1e3)
+                if chains <= 0:
+                    times[name].append((c.gram_bench(reps=iters) if chains == 0
+                                        else c.residual_rss_bench(nb=1, reps=iters)) * 1e3)
                     out, st = c.gram(), {"groups_per_chain": 0, "waves_per_group": 0,
                                          "chains_per_pass": 0, "residency": 0}
                 else:

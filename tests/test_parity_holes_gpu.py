@@ -114,6 +114,25 @@ def test_t1_gram_at_k256():
     assert rel(ctx.gram(), Xa.T @ Xa) < 1e-12
 
 
+@pytest.mark.parametrize("n,k", [(3, 2), (1237, 5), (4097, 47), (3000, 63), (7000, 79), (6000, 95),
+                                 (9000, 130), (5000, 143), (5000, 144), (8000, 160), (2000, 255)])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_t1_gram_every_tile_class(n, k, dt):
+    """The Gram kernel chooses accumulators per wave, tile sets and row parts from the tile count
+    (kernels_setup.hip, gram_geometry): one shape per class -- 6 / 8 / 10 / 20 accumulators, the
+    row dimension split over waves or not, 64- and 32-row sub-panels, ragged row counts -- in f64
+    and f32 storage against numpy (reference inference_utils.py:25,43: X.T.dot(X), X.T.dot(y))."""
+    ctx = gpu_ctx()
+    rng = np.random.Generator(np.random.PCG64(n + k))
+    X = rng.standard_normal((n, k)).astype(dt)
+    y = rng.standard_normal(n).astype(dt)
+    ctx.set_problem(y, np.asfortranarray(X), dtype=dt)
+    Xa = np.column_stack([X.astype(np.float64), y.astype(np.float64)])
+    got = ctx.gram()
+    assert rel(got, Xa.T @ Xa) < 1e-12
+    assert np.array_equal(got, got.T)
+
+
 @pytest.mark.parametrize("res", [0, 3])
 def test_t2_replay_k256(res):
     """The oracle chain at K = 256 (N = 2000, dense prior covariance) through the HIP loop,
