@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bmc_math.h"
+
 namespace bmc {
 
 constexpr int WAVE = 64;

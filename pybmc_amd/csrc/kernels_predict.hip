@@ -52,12 +52,7 @@ __device__ __forceinline__ void pg_noise(uint64_t e, uint32_t k0, uint32_t k1, d
                                          double& z1) {
     const u32x4 r = philox4x32_10(u32x4{(uint32_t)e, (uint32_t)(e >> 32), STREAM_PRED_NORMAL, 0u},
                                   k0, k1);
-    const double u1 = u53_open0(r.x, r.y), u2 = u53_open0(r.z, r.w);
-    const double rad = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    z0 = rad * cs;
-    z1 = rad * sn;
+    box_muller_pair(u53_open0(r.x, r.y), u53_open0(r.z, r.w), z0, z1);   // bmc_math.h
 }
 
 __global__ __launch_bounds__(256) void predict_gemm_kernel(

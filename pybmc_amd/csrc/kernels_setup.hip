@@ -727,12 +727,7 @@ hipError_t launch_unrotate(const double* uout, const double* WT, int32_t k, int6
 // so a chain's variates depend on (seed, e) only -- not on the launch geometry,
 // the chain's index or the number of GPUs.
 __device__ __forceinline__ void box_muller(u32x4 r, double& z0, double& z1) {
-    const double u1 = u53_open0(r.x, r.y), u2 = u53_open0(r.z, r.w);
-    const double rad = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    z0 = rad * cs;
-    z1 = rad * sn;
+    box_muller_pair(u53_open0(r.x, r.y), u53_open0(r.z, r.w), z0, z1);   // bmc_math.h
 }
 
 __global__ __launch_bounds__(256) void normal_fill_kernel(const uint64_t* __restrict__ seeds,
