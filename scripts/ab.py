@@ -42,6 +42,11 @@ CASES = {   # name: (problem factory, dtype, chains, iterations)
     "n100k": (lambda: dense(100000, 32, np.float64), np.float64, 1, 5000),
     "n100kx8": (lambda: dense(100000, 32, np.float64), np.float64, 8, 2000),
     "small": (lambda: synth(629, 3), np.float64, 1, 50000),
+    # more chains that span XCDs (G > 32), register-resident
+    "n30k64": (lambda: dense(30000, 64, np.float64), np.float64, 1, 5000),
+    "n200k32": (lambda: dense(200000, 32, np.float64), np.float64, 1, 3000),
+    "n100k64f32": (lambda: dense(100000, 64, np.float32), np.float32, 1, 4000),
+    "n60k16": (lambda: dense(60000, 16, np.float64), np.float64, 1, 5000),
     # chains = 0: time the one-off Gram [X y]'[X y] (f64 MFMA) instead of the loop, us per launch
     "gram_c2": (lambda: synth(10000, 32), np.float64, 0, 50),
     "gram_c4": (lambda: dense(200000, 64, np.float32), np.float32, 0, 20),
