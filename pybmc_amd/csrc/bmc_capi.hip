@@ -316,6 +316,11 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
                 }
             }
             if (G > MAX_GROUPS_PER_LAUNCH) continue;
+            // a chain over several XCDs: whole teams (groups g mod 8), so that the kernel can
+            // put team j on XCD j whichever XCD the launch starts on
+            if (tu.groups_per_chain <= 0 && G > CU_PER_XCD && XCD_COUNT == 8 &&
+                ((G + 7) & ~7) <= MAX_GROUPS_PER_LAUNCH)
+                G = (G + 7) & ~7;
             const int ppg_reg = (NP + G - 1) / G;
             int waves = tu.waves_per_group > 0 ? tu.waves_per_group : (ppg_reg + ppw - 1) / ppw;
             if (waves > 8 || (int64_t)G * waves * ppw < NP) continue;
@@ -355,6 +360,7 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
         if (G < 1) G = 1;
         if (!lds_fits(G) && lds_fits(gmax))
             while (!lds_fits(G)) ++G;
+        if (G > CU_PER_XCD && XCD_COUNT == 8 && ((G + 7) & ~7) <= gmax) G = (G + 7) & ~7;   // whole teams
     }
     if (G > NP) G = NP;
     g.G = G;

@@ -178,6 +178,36 @@ __device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, i
     return __all(same) ? 1 : 0;
 }
 
+// Which XCD did the hardware start this launch's round robin on?  Workgroup b of a launch runs
+// on XCD (b + c) mod 8, with c depending on the queue (HIP stream) and its history
+// (scripts/micro/xcc_map.hip).  Every workgroup publishes the XCC id it runs on under its BLOCK
+// index and reads all G of them; the answer is c if the placement really is that rotation, -1
+// otherwise (or when the bounded spin expired) -- data every workgroup reads identically, so all
+// take the same decision.  Run by wave 0.
+__device__ __forceinline__ int detect_rotation(gu64* words, int G, int b, int lane) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    if (lane == 0)
+        __hip_atomic_store(words + b, (gu64)(xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long t_start = 0;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true, rot = true;
+        const gu64 w0 = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int base = 0; base < G; base += 64) {
+            const int idx = base + lane;
+            gu64 w = 1;
+            if (idx < G) w = __hip_atomic_load(words + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && w != 0 && w0 != 0;
+            rot = rot && (idx >= G || ((w - 1) & 7) == ((w0 - 1 + (gu64)idx) & 7));
+        }
+        if (__all(ok)) return __all(rot) ? (int)((w0 - 1) & 7) : -1;
+        if ((spins & 0xff) == 0xff) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_start == 0) t_start = now;
+            else if (now - t_start > SPIN_TIMEOUT_TICKS) return -1;
+        }
+    }
+}
+
 // ---- partial rss of one panel, data in memory (LDS or global) ---------------------
 template <typename T, int VEC, bool NT = false>
 __device__ __forceinline__ double panel_rss(const T* __restrict__ xp, const T* __restrict__ yp,

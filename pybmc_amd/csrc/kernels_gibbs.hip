@@ -107,12 +107,31 @@ void gibbs_loop_kernel(GibbsArgs a) {
     const int C = a.n_chains, G = a.G;
     // nslot = 8: slot label, blocks b and b+8 share an XCD (observed); nslot = C otherwise
     const int chain = blockIdx.x % a.nslot;
-    const int g = blockIdx.x / a.nslot;
+    int g = blockIdx.x / a.nslot;
     if (chain >= C) return;                // unused slot: the whole workgroup leaves
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
     const int64_t T_it = a.iters;
+#ifndef BMC_NO_XCD_REMAP
+    // One chain over the whole chip (G > 32, a multiple of 8): team j = the groups with g mod 8 = j
+    // is meant to be the groups of XCD j.  The hardware deals the workgroups of a launch round
+    // robin, but starts at an XCD that depends on the queue: renumber the groups so that group
+    // g' = 8 (b / 8) + (XCC id of block b) -- team j then runs on XCD j whatever the start was
+    // (measured: 2.02 us per iteration at N = 100 000 x 32 with team j on XCD j, 2.25 rotated by
+    // 5 to 7; C4 3.28 vs 3.45-3.55).  Falls back to g = b when the placement is not a rotation.
+    if constexpr (!SINGLE && !SMALLG) {
+        if (G > 32 && (G & 7) == 0 && a.nslot == 1) {
+            __shared__ int rot_c;
+            if (wave == 0) {
+                const int c = detect_rotation(a.gran + (size_t)2 * a.gran_stride + 256, G, g, lane);
+                if (lane == 0) rot_c = c;
+            }
+            __syncthreads();
+            if (rot_c >= 0) g = (g & ~7) | ((g + rot_c) & 7);
+        }
+    }
+#endif
 
     const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, MODE == MODE_LDS);
     double* u_lds = reinterpret_cast<double*>(smem + L.u);
@@ -313,11 +332,23 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     constexpr int KCH = (MODE == MODE_REG) ? 1 : MAX_KCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = a.P.k, G = a.G;
-    const int g = blockIdx.x;             // one bundle of CPP chains per launch
+    int g = blockIdx.x;                   // one bundle of CPP chains per launch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
     const int64_t T_it = a.iters;
+#ifndef BMC_NO_XCD_REMAP
+    // team j on XCD j whichever XCD the launch starts on (see gibbs_loop_kernel)
+    if (G > 32 && (G & 7) == 0) {
+        __shared__ int rot_c;
+        if (wave == 0) {
+            const int c = detect_rotation(a.gran + (size_t)2 * a.gran_stride + 256, G, g, lane);
+            if (lane == 0) rot_c = c;
+        }
+        __syncthreads();
+        if (rot_c >= 0) g = (g & ~7) | ((g + rot_c) & 7);
+    }
+#endif
 
     const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, MODE == MODE_LDS, 0, CPP);
     double* u_lds = reinterpret_cast<double*>(smem + L.u);   // [CPP][kpad]
