@@ -14,8 +14,19 @@ constexpr int GRAN_PAIR_STRIDE = BMC_GRAN_PAIR_STRIDE;
 // u64 words of one (chain, parity) exchange slot: G <= 32 groups use pairs 0..G-1; larger
 // chains use 8 team areas of 32 pairs, 8 team-total pairs and 8 relay pairs (bmc_loop.h,
 // exchange_sum)
+// (the 8 team-total pairs and the 8 relay pairs of the second level are written by one XCD each
+// and polled by every group of the chain at agent scope: GRAN_L2_STRIDE words = 512 bytes
+// apart.  Same-box A/B, us per iteration at 64 B / 128 B / 256 B / 512 B / 1 KiB per pair:
+// N = 100 000 x 32 2.005 / 1.988 / 1.945 / 1.881 / 1.919, C4 3.291 / 3.241 / 3.156 / 3.131 / 3.164,
+// N = 30 000 x 64 2.112 / 2.069 / 2.038 / 1.986 / 2.073 -- the polls of ~200 groups spread over
+// the memory channels instead of landing on one or two)
+#ifndef BMC_GRAN_L2_STRIDE
+#define BMC_GRAN_L2_STRIDE 64
+#endif
+constexpr int GRAN_L2_STRIDE = BMC_GRAN_L2_STRIDE;
 inline int gran_slot_words(int G) {
-    return (G <= 32 ? ((2 * G + 31) / 32) * 16 : 256 + 8 + 8) * GRAN_PAIR_STRIDE;
+    return G <= 32 ? ((2 * G + 31) / 32) * 16 * GRAN_PAIR_STRIDE
+                   : 256 * GRAN_PAIR_STRIDE + 16 * GRAN_L2_STRIDE;
 }
 
 struct Panels {

@@ -73,8 +73,9 @@ __host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bo
 // (sc1, write-through) and visible to every XCD.
 // Granule i of a (chain, parity) slot: the pair (high word, low word) of group i/2 sits
 // GRAN_PAIR_STRIDE words after the pair of group i/2 - 1.
+template <int STRIDE = GRAN_PAIR_STRIDE>
 __device__ __forceinline__ size_t gran_at(int i) {
-    return (size_t)(i >> 1) * GRAN_PAIR_STRIDE + (i & 1);
+    return (size_t)(i >> 1) * STRIDE + (i & 1);
 }
 
 template <bool LOCAL>
@@ -96,12 +97,12 @@ __device__ __forceinline__ void granule_put(gu64* g, unsigned epoch, unsigned va
 // kept in flight, so the epoch is seen half a load round trip after it lands instead of up
 // to a full one (three or four in flight were slower: same-box A/B).  Returns false when the
 // bounded spin expired.  Lanes >= n2 get 0.
-template <int DEPTH = 2>
+template <int DEPTH = 2, int STRIDE = GRAN_PAIR_STRIDE>
 __device__ __forceinline__ bool granule_gather1(const gu64* gp, int n2, unsigned epoch, int lane,
                                                 gu64& x STAMP_PARAMS) {
     unsigned long long t_start = 0;
     const bool have = lane < n2;
-    const gu64* p = gp + gran_at(have ? lane : 0);
+    const gu64* p = gp + gran_at<STRIDE>(have ? lane : 0);
     gu64 q[DEPTH];
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) q[d] = granule_load(p);
@@ -521,11 +522,11 @@ __device__ __forceinline__ double sum_wave_slots(const double* red, int lane) {
     return readlane_f64(v, 0);
 }
 
-template <bool LOCAL>
+template <bool LOCAL, int STRIDE = GRAN_PAIR_STRIDE>
 __device__ __forceinline__ void publish_pair(gu64* gp, int g, int lane, unsigned epoch, double s) {
     if (lane < 2) {   // lane 0 the high word, lane 1 the low word: one store instruction
         const unsigned w = lane == 0 ? (unsigned)__double2hiint(s) : (unsigned)__double2loint(s);
-        granule_put<LOCAL>(gp + gran_at(2 * g + lane), epoch, w);
+        granule_put<LOCAL>(gp + gran_at<STRIDE>(2 * g + lane), epoch, w);
     }
 }
 
@@ -577,18 +578,20 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     GSTAMP(5);
     double tot = ok ? granule_sum1(x, lane) : 0.0;
     if (teams && ok) {
-        gu64* gp2 = gp + gran_at(2 * 256);
-        gu64* gp3 = gp + gran_at(2 * (264 + team));
-        if (rank == 0) publish_pair<false>(gp2, team, lane, epoch, tot);
+        // second level: 8 team-total pairs, then 8 relay pairs, GRAN_L2_STRIDE words (512 bytes)
+        // apart: each pair is written by one XCD and polled by all (bmc_launch.h)
+        gu64* gp2 = gp + (size_t)256 * GRAN_PAIR_STRIDE;
+        gu64* gp3 = gp2 + (size_t)(8 + team) * GRAN_L2_STRIDE;
+        if (rank == 0) publish_pair<false, GRAN_L2_STRIDE>(gp2, team, lane, epoch, tot);
         if (!RELAY || rank == 0) {
-            ok = granule_gather1<BMC_POLL_DEPTH2>(gp2, 16, epoch, lane, x STAMP_ARGS);
+            ok = granule_gather1<BMC_POLL_DEPTH2, GRAN_L2_STRIDE>(gp2, 16, epoch, lane, x STAMP_ARGS);
             tot = ok ? granule_sum1(x, lane) : 0.0;
             if (RELAY && ok) {
-                if (local) publish_pair<true>(gp3, 0, lane, epoch, tot);
-                else publish_pair<false>(gp3, 0, lane, epoch, tot);
+                if (local) publish_pair<true, GRAN_L2_STRIDE>(gp3, 0, lane, epoch, tot);
+                else publish_pair<false, GRAN_L2_STRIDE>(gp3, 0, lane, epoch, tot);
             }
         } else {
-            ok = granule_gather1(gp3, 2, epoch, lane, x STAMP_ARGS);
+            ok = granule_gather1<2, GRAN_L2_STRIDE>(gp3, 2, epoch, lane, x STAMP_ARGS);
             tot = ok ? granule_sum1(x, lane) : 0.0;   // the relayed double itself (+ zeros)
         }
     }
