@@ -190,9 +190,9 @@ int check_problem_args(bmc_ctx* c, const void* X, int64_t n, int32_t k, int64_t 
 
 int ensure_ticket(bmc_ctx* c) {
     if (c->ticket.p) return BMC_OK;
-    int rc = ensure(c, c->ticket, 64);
+    int rc = ensure(c, c->ticket, bmc::RSS_TICKET_BYTES);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->ticket.p, 0, 64, c->stream));  // the kernel keeps it zero
+    HIPCHK(c, hipMemsetAsync(c->ticket.p, 0, bmc::RSS_TICKET_BYTES, c->stream));  // the kernel keeps it zero
     return BMC_OK;
 }
 

@@ -65,8 +65,11 @@ hipError_t launch_unpanelize(const double* Xp, int64_t n, int32_t k, int32_t vec
                              hipStream_t s);
 
 // rss[b] = sum_i (y_i - sum_j X_ij coef[b][j])^2, b < nb (nb <= 8), one launch.
-// partial: >= rss_groups(P) * 8 doubles of scratch; ticket_word: one zeroed u32 that
+// partial: >= rss_groups(P) * 8 doubles of scratch; ticket_word: RSS_TICKET_BYTES of zeroed u32 that
 // the kernel leaves zero again.
+constexpr int RSS_TICKETS = 16, RSS_TICKET_STRIDE = 128;   // u32 words: 512 bytes between ticket words
+constexpr unsigned RSS_FLAT_TICKET_MAX = 256;   // more workgroups than this draw tickets in two levels
+constexpr size_t RSS_TICKET_BYTES = (size_t)(RSS_TICKETS + 1) * RSS_TICKET_STRIDE * 4;
 int32_t rss_groups(const Panels& P);
 hipError_t launch_residual_rss(const Panels& P, const double* coef, int32_t nb,
                                double* partial, unsigned* ticket_word, double* rss_out,

@@ -602,11 +602,36 @@ __global__ __launch_bounds__(256) void residual_rss_kernel(
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned ticket = 0;
-    if (lane == 0)
-        ticket = __hip_atomic_fetch_add(ticket_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != gridDim.x - 1) return;
+    // Up to 256 workgroups draw one ticket.  More than that (C4: 391) finish almost together, and
+    // hundreds of atomic adds on ONE word are served one after the other (~30 cycles each,
+    // scripts/micro/atomic_allreduce.hip) -- a tail of microseconds behind the last byte read
+    // (C4: 11.9 -> 9.7 us per pass with two levels; with 196 or 40 workgroups the second hop costs
+    // 0.2-0.3 us more than it saves).  Two levels: workgroup b draws from word 1 + b mod 16 (the
+    // words 512 bytes apart), the last of each draws from word 0, the last of those sums.  Every
+    // word is left zero by the workgroup that completed it.
+    if (gridDim.x <= RSS_FLAT_TICKET_MAX) {
+        unsigned ticket = 0;
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(ticket_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != gridDim.x - 1) return;
+    } else {
+        const unsigned sub = blockIdx.x & (RSS_TICKETS - 1);
+        const unsigned n_sub = (gridDim.x - sub + RSS_TICKETS - 1) / RSS_TICKETS;
+        unsigned* tw = ticket_word + (size_t)(1 + sub) * RSS_TICKET_STRIDE;
+        unsigned ticket = 0;
+        if (lane == 0)
+            ticket = __hip_atomic_fetch_add(tw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != n_sub - 1) return;
+        unsigned top = 0;
+        if (lane == 0) {
+            __hip_atomic_store(tw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            top = __hip_atomic_fetch_add(ticket_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        top = __builtin_amdgcn_readfirstlane(top);
+        if (top != RSS_TICKETS - 1) return;
+    }
     const int ngroups = gridDim.x;   // <= 1024: at most 16 partials per lane
     const unsigned long long* pw = reinterpret_cast<const unsigned long long*>(partial);
     for (int b = 0; b < nb; ++b) {
