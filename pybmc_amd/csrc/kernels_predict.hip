@@ -202,7 +202,13 @@ __global__ __launch_bounds__(1024) void predict_orderstat_kernel(
 // are elements of the row, so the result is bit-identical to the sort.  A point whose requested
 // bin holds more than SEL_CAP draws (heavy ties, far outliers) is handed to the sort kernel
 // through `fail_points`.
-constexpr int SEL_BINS = 2048, SEL_CAP = 64, SEL_THREADS = 512;
+// (bins: same-box A/B of the C5 order statistics with 2048 / 4096 / 8192 bins: 1.88 / 1.62 / 2.59 ms --
+// half the draws per requested bin halve the rank counting; 8192 bins leave one workgroup per CU)
+#ifndef BMC_SEL_BINS
+#define BMC_SEL_BINS 4096
+#endif
+constexpr int SEL_BINS = BMC_SEL_BINS, SEL_CAP = 64, SEL_THREADS = 512;
+constexpr int SEL_BPT = SEL_BINS / SEL_THREADS;   // consecutive bins per thread in the prefix sums
 
 __device__ __forceinline__ int sel_bin(double x, double mn, double scale) {
     const double t = (x - mn) * scale;
@@ -227,7 +233,8 @@ __global__ __launch_bounds__(SEL_THREADS, VPT > 24 ? 2 : 4) void predict_select_
     double* red = reinterpret_cast<double*>(slot + SEL_BINS);  // [16] min / max per wave
     unsigned* wsum = reinterpret_cast<unsigned*>(red + 16);    // [8] wave totals of the scan
     unsigned* flag = wsum + 8;                                 // [0] overflow
-    unsigned* cnt = flag + 8;                                  // [n_t] members per list
+    unsigned* pbase = flag + 8;                                // [SEL_THREADS] exclusive prefix per thread
+    unsigned* cnt = pbase + SEL_THREADS;                       // [n_t] members per list
     int* tbin = reinterpret_cast<int*>(cnt + n_t);             // [n_t] bin of rank t
     int* tk = tbin + n_t;                                      // [n_t] rank inside that bin
     int* trank = tk + n_t;                                     // [n_t] the requested ranks
@@ -288,11 +295,13 @@ __global__ __launch_bounds__(SEL_THREADS, VPT > 24 ? 2 : 4) void predict_select_
         }
         __syncthreads();
         if (usable) {
-            // exclusive prefix sums over the bins, 4 consecutive bins per thread; the thread whose
-            // 4 bins contain a requested rank records its bin (no search, no second pass)
-            const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * tid);
-            const unsigned h[4] = {h4.x, h4.y, h4.z, h4.w};
-            const unsigned tot = h[0] + h[1] + h[2] + h[3];
+            // exclusive prefix sums over the bins, SEL_BPT consecutive bins per thread
+            unsigned tot = 0;
+#pragma unroll
+            for (int q = 0; q < SEL_BPT; q += 4) {
+                const uint4 h4 = *reinterpret_cast<const uint4*>(hist + SEL_BPT * tid + q);
+                tot += (h4.x + h4.y) + (h4.z + h4.w);
+            }
             unsigned inc = tot;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -303,16 +312,25 @@ __global__ __launch_bounds__(SEL_THREADS, VPT > 24 ? 2 : 4) void predict_select_
             __syncthreads();
             unsigned base = inc - tot;
             for (int w = 0; w < wave; ++w) base += wsum[w];
-            for (int t = 0; t < n_t; ++t) {
-                const unsigned r = (unsigned)trank[t];
-                if (r >= base && r < base + tot) {   // exactly one thread
-                    unsigned b0 = base;
-                    int j = 0;
-                    while (r >= b0 + h[j]) { b0 += h[j]; ++j; }
-                    tbin[t] = 4 * tid + j;
-                    tk[t] = (int)(r - b0);
-                    atomicMin(&slot[4 * tid + j], (unsigned)t);
+            // Thread t < n_t finds the bin of requested rank t: a binary search over the threads'
+            // exclusive prefixes (left in LDS), then the few bins of that thread.  (Every thread
+            // testing every rank against its own 4 bins, as before, was n_t iterations in all 8
+            // waves: a quarter of the kernel's vector instructions.)
+            pbase[tid] = base;
+            __syncthreads();
+            if (tid < n_t) {
+                const unsigned r = (unsigned)trank[tid];
+                int lo = 0, hi = SEL_THREADS - 1;      // last thread whose prefix is <= r
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (pbase[mid] <= r) lo = mid; else hi = mid - 1;
                 }
+                unsigned b0 = pbase[lo];
+                int j = 0;
+                while (j < SEL_BPT - 1 && r >= b0 + hist[SEL_BPT * lo + j]) { b0 += hist[SEL_BPT * lo + j]; ++j; }
+                tbin[tid] = SEL_BPT * lo + j;
+                tk[tid] = (int)(r - b0);
+                atomicMin(&slot[SEL_BPT * lo + j], (unsigned)tid);
             }
             __syncthreads();
             // members of the requested bins -> their lists (slot words read in one batch)
@@ -411,7 +429,7 @@ hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
         int64_t blocks = a.M < 2048 ? a.M : 2048;
         if (blocks < 1) blocks = 1;
         if (select) {
-            const size_t lds = (size_t)SEL_BINS * 8 + 16 * 8 + 16 * 4 + (size_t)n_t * 16 + 16 +
+            const size_t lds = (size_t)SEL_BINS * 8 + 16 * 8 + 16 * 4 + SEL_THREADS * 4 + (size_t)n_t * 16 + 16 +
                                (size_t)n_t * SEL_CAP * 8;
 #define BMC_SEL(V)                                                                             \
     do {                                                                                       \
