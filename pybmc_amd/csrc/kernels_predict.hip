@@ -339,12 +339,12 @@ __global__ __launch_bounds__(SEL_THREADS, VPT > 24 ? 2 : 4) void predict_select_
             double scale2 = scale;
             asm volatile("" : "+v"(scale2));
 #pragma unroll
-            for (int i0 = 0; i0 < VPT; i0 += 8) {
-                unsigned sl[8];
+            for (int i0 = 0; i0 < VPT; i0 += 4) {
+                unsigned sl[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) sl[i] = slot[sel_bin(v[i0 + i], mn, scale2)];
+                for (int i = 0; i < 4; ++i) sl[i] = slot[sel_bin(v[i0 + i], mn, scale2)];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 4; ++i)
                     if (sl[i] != ~0u && tid + (i0 + i) * SEL_THREADS < S) {
                         const unsigned pos = atomicAdd(&cnt[sl[i]], 1u);
                         if (pos < SEL_CAP) list[sl[i] * SEL_CAP + pos] = v[i0 + i];
@@ -442,9 +442,14 @@ hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
                            a.bands, a.hits, a.fail_points, a.fail_count);                      \
     } while (0)
             const int vpt = (a.S + SEL_THREADS - 1) / SEL_THREADS;
+            // draws per thread in steps of 4 (10 000 draws: 20, not 24 -- the slots past the row
+            // cost every per-draw step of the kernel)
             if (vpt <= 8) BMC_SEL(8);
+            else if (vpt <= 12) BMC_SEL(12);
             else if (vpt <= 16) BMC_SEL(16);
+            else if (vpt <= 20) BMC_SEL(20);
             else if (vpt <= 24) BMC_SEL(24);
+            else if (vpt <= 28) BMC_SEL(28);
             else BMC_SEL(32);
 #undef BMC_SEL
             e = hipGetLastError();
