@@ -361,6 +361,55 @@ struct PanelStore {
                                                           double (&s)[CPP]) const {
         static_assert(MODE == MODE_REG, "register residency only");
         typedef const __attribute__((address_space(3))) double lds_cd;
+#ifndef BMC_REGMULTI_LDS
+        // From 16 columns on: u through DPP row broadcasts, as in partial_rss -- per chain one
+        // ds_read_b64 per 16 columns (lane l <- u[c][16 r + (l & 15)]) instead of one LDS broadcast
+        // read per (chain, column).  With 4 chains x 64 columns (C4) that was 256 reads per wave
+        // and pass, 4096 cycles of the CU's LDS pipe beside ~3000 cycles of FMAs and conversions.
+        // Per chain the operations and their order are those of partial_rss (acc + u (-x) ==
+        // fma(-x, u, acc)), so a chain's bits do not depend on how many chains share the pass.
+        if constexpr (KMAX >= 16) {
+            lds_cd* ub = (lds_cd*)u;
+            constexpr int NU = (KMAX + 15) / 16;
+#pragma unroll
+            for (int c = 0; c < CPP; ++c) {
+                double urow[NU];
+#pragma unroll
+                for (int r = 0; r < NU; ++r) urow[r] = ub[c * kpad + r * 16 + (lane & 15)];
+                // (pinned where they are loaded: the DPP statements are opaque to hipcc, which
+                // otherwise re-reads u from LDS in front of every one of them)
+#pragma unroll
+                for (int r = 0; r < NU; ++r) asm volatile("" : "+v"(urow[r]));
+                double acc[PPW][VEC][4];
+#pragma unroll
+                for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        acc[i][v][0] = (double)yr[i][v];
+                        acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
+                    }
+                static_for<KMAX>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            fmac_rowbcast_neg<j % 16, (j % 16 == 0)>(acc[i][v][j % 4], urow[j / 16],
+                                                                   as_f64_in_loop(xr[i][j][v]));
+                });
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double r = (acc[i][v][0] + acc[i][v][1]) + (acc[i][v][2] + acc[i][v][3]);
+                        t = fma(r, r, t);
+                    }
+                s[c] = t;
+            }
+            return;
+        }
+#endif
         // blocks of UB values of u, DEPTH blocks in flight (fewer where the panel already
         // fills 128 VGPRs)
         // (Stamps: the pass is LDS-latency bound, one block of u at a time -- the volatile asm
