@@ -29,8 +29,17 @@ __global__ __launch_bounds__(256) void predict_weights_kernel(
         double v = 0.0;
         if (s < S && m < Km) {
             const double* th = theta + (int64_t)s * (k + 1);
-            for (int i = 0; i < k; ++i) v = fma(th[i], Vt[(size_t)i * Km + m], v);
-            v += w0;
+            // four independent chains (a single one is k dependent FMAs: latency-bound)
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int i = 0;
+            for (; i + 3 < k; i += 4) {
+                v0 = fma(th[i], Vt[(size_t)i * Km + m], v0);
+                v1 = fma(th[i + 1], Vt[(size_t)(i + 1) * Km + m], v1);
+                v2 = fma(th[i + 2], Vt[(size_t)(i + 2) * Km + m], v2);
+                v3 = fma(th[i + 3], Vt[(size_t)(i + 3) * Km + m], v3);
+            }
+            for (; i < k; ++i) v0 = fma(th[i], Vt[(size_t)i * Km + m], v0);
+            v = ((v0 + v1) + (v2 + v3)) + w0;
         }
         Wt[e] = v;
         if (m == 0) sig[s] = s < S ? theta[(int64_t)s * (k + 1) + k] : 0.0;
