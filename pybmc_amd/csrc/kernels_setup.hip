@@ -383,14 +383,21 @@ constexpr int ROT_JT = 8;
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void rotate_kernel(const T* __restrict__ X,
                                                      const double* __restrict__ W, int32_t K,
-                                                     int32_t KO, T* __restrict__ Xrot) {
+                                                     int32_t KO, T* __restrict__ Xrot,
+                                                     int32_t npanels, uint32_t ncg) {
     // W is [K][KO] row-major; the output panels have KO columns
     constexpr int RP = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j0 = (blockIdx.y * 4 + wave) * ROT_JT;
-    if (j0 >= KO) return;
-    const int64_t p = blockIdx.x;
+    // XCD-aware order: the ncg workgroups that produce the column groups of ONE panel all read
+    // that panel.  The hardware deals workgroups to the 8 XCDs round robin, so they are made 8
+    // apart in launch order (block b: XCD b mod 8 takes panels b mod 8, 8 + b mod 8, ...; its
+    // consecutive workgroups are the column groups of one panel): the panel comes from memory
+    // once, not once per XCD (C5: 836 MB fetched for a 103 MB matrix before).
+    const unsigned b = blockIdx.x;
+    const int64_t p = (int64_t)((b >> 3) / ncg) * 8 + (b & 7);
+    const int j0 = (int)(((b >> 3) % ncg) * 4 + wave) * ROT_JT;
+    if (p >= npanels || j0 >= KO) return;
     const T* xp = X + p * (int64_t)K * RP + lane * VEC;
     double acc[ROT_JT][VEC];
 #pragma unroll
@@ -419,10 +426,11 @@ __global__ __launch_bounds__(256) void rotate_kernel(const T* __restrict__ X,
 template <typename T>
 static hipError_t rotate_dispatch(const Panels& P, const double* W, int32_t ko, void* Xrot,
                                   hipStream_t s) {
-    dim3 grid(P.npanels, (ko + 4 * ROT_JT - 1) / (4 * ROT_JT));
+    const uint32_t ncg = (uint32_t)((ko + 4 * ROT_JT - 1) / (4 * ROT_JT));   // column groups per panel
+    const dim3 grid((unsigned)(((P.npanels + 7) / 8) * 8) * ncg);
 #define BMC_ROT(V)                                                                       \
     hipLaunchKernelGGL((rotate_kernel<T, V>), grid, dim3(256), 0, s, (const T*)P.X, W, P.k, \
-                       ko, (T*)Xrot)
+                       ko, (T*)Xrot, P.npanels, ncg)
     switch (P.vec) {
         case 1: BMC_ROT(1); break;
         case 2: BMC_ROT(2); break;
