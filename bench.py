@@ -54,6 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank, so that the "
                          "collective leg runs on a one-GPU box")
+    ap.add_argument("--fail-rank", type=int, default=-1,
+                    help="test hook: this rank exits with status 3 before the rendezvous (what a "
+                         "missing device or a failed RCCL init looks like to the parent)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="rehearse the launch / rendezvous / pooling plumbing on the CPU with "
                          "gloo and a stand-in for the sampler; measures nothing")
@@ -70,35 +73,87 @@ def free_port():
 def spawn_ranks(args, argv):
     """Parent of a plain ``python bench.py --gpus N``: start N rank children (fresh
     interpreters, one per GPU), relay rank 0's stdout, exit with the worst return code.
-    The parent imports neither torch nor the HIP library."""
+    The parent imports neither torch nor the HIP library.
+
+    Fail fast: every child is polled.  As soon as ANY rank exits non-zero (device missing,
+    RCCL init error, a sampler status) the others -- which would otherwise sit in the
+    rendezvous or in a collective until torch's own timeout -- are killed at once, the failed
+    rank and the tail of its output are printed on stderr, and the parent exits non-zero.
+    Ranks other than 0 write to per-rank log files (gpurun_out/bench_rank<r>.log), not to
+    /dev/null, so their failure text survives."""
+    import tempfile
     port = free_port()
-    procs = []
+    logdir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(logdir, exist_ok=True)
+        if not os.access(logdir, os.W_OK):
+            raise OSError
+    except OSError:
+        logdir = tempfile.mkdtemp(prefix="bench_ranks_")
+    procs, logs = [], []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        # stdout AND stderr of every rank into its own file: nothing blocks on a full pipe
+        # while the parent polls, and a dead rank's last words can be shown
+        path = os.path.join(logdir, f"bench_rank{r}.log")
+        f = open(path, "w+b")
+        logs.append((path, f))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
-                                      env=env, stdout=out, stderr=None, cwd=ROOT))
+                                      env=env, stdout=f, stderr=subprocess.STDOUT, cwd=ROOT))
+
+    def tail(r, n=2500):
+        f = logs[r][1]
+        f.flush()
+        f.seek(0, os.SEEK_END)
+        size = f.tell()
+        f.seek(max(0, size - n))
+        return f.read().decode("utf-8", "replace")
+
     deadline = time.monotonic() + args.rank_timeout_s
-    rc = 0
-    line = b""
+    rc, failed = 0, None
     try:
-        line, _ = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))
-        for p in procs:
-            p.wait(timeout=max(1.0, deadline - time.monotonic()))
-            rc = rc or p.returncode
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                rc = codes[failed] if codes[failed] > 0 else 1      # (killed by a signal: < 0)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                rc = 124
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:      # exactly the children started above, by PID
             if p.poll() is None:
                 p.kill()
                 p.wait()
-    sys.stdout.write(line.decode("utf-8", "replace"))
-    sys.stdout.flush()
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed} exited with status {procs[failed].returncode}; "
+                         f"the other ranks were stopped.  Last output of rank {failed} "
+                         f"({logs[failed][0]}):\n{tail(failed)}\n")
+    elif rc == 124:
+        sys.stderr.write(f"bench.py: ranks still running after --rank-timeout-s "
+                         f"{args.rank_timeout_s:.0f}; stopped.  Rank 0 said:\n{tail(0)}\n")
+    else:
+        # rank 0's JSON line (and nothing else of its chatter) is the parent's stdout
+        f = logs[0][1]
+        f.flush()
+        f.seek(0)
+        for ln in f.read().decode("utf-8", "replace").splitlines():
+            if ln.startswith("{"):
+                sys.stdout.write(ln + "\n")
+            elif ln.strip():
+                sys.stderr.write(ln + "\n")
+        sys.stdout.flush()
+    for _, f in logs:
+        f.close()
     return rc
 
 
@@ -123,7 +178,7 @@ def profiled_traffic(kernel_substr):
             if kernel_substr in name and "hbm_read_bytes_per_launch" in e:
                 return {"bytes_per_launch": e["hbm_read_bytes_per_launch"]
                         + e.get("hbm_write_bytes_per_launch", 0.0),
-                        "source": os.path.basename(files[-1]),
+                        "source": os.path.basename(files[-1]), "kernel": name,
                         "profiled_avg_ms": e["avg_ms"]}
     except Exception:
         return None
@@ -224,6 +279,14 @@ def rank_main(args):
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     dry = args.dry_run_cpu
     backend = "gloo" if dry else "nccl"
+    if args.fail_rank == rank:
+        sys.stderr.write(f"rank {rank}: --fail-rank test hook, leaving before the rendezvous\n")
+        raise SystemExit(3)
+    if not dry and torch.cuda.device_count() < max(world, local_rank + 1):
+        # checked BEFORE init_process_group: a rank without a device must not leave the others
+        # waiting in the rendezvous (device_count() does not initialise the GPU)
+        raise SystemExit(f"rank {rank}: {torch.cuda.device_count()} GPU(s) visible, "
+                         f"world size {world} needs one per rank")
     if dry:
         dev = torch.device("cpu")
     else:
@@ -350,6 +413,11 @@ def rank_main(args):
             line["roofline"] = roofline_entry(st, avg_loop_ms, float(np.mean(bytes_moved)), N, K, T)
             if world == 1 and not args.no_extra:
                 line["extra"] = extras(ctx, torch, dev, local_rank, N, K, T)
+                # the kernel BASELINE.json's north_star names for the HBM roofline (>= 40 %): the
+                # residual reduction at the C4 size, as a roofline block of its own
+                rc4 = line["extra"].pop("residual_rss_c4", None)
+                if rc4 and "error" not in rc4:
+                    line["roofline_residual_c4"] = residual_roofline(rc4)
             if world == 1 and not args.no_cpu_baseline:
                 cb = cpu_baseline(prob, budget_s=args.cpu_budget_s)
                 line["cpu_baseline"] = cb
@@ -370,9 +438,14 @@ def roofline_entry(st, avg_loop_ms, alg_bytes, N, K, T):
     us_it = avg_loop_ms * 1e3 / T
     tr = profiled_traffic("gibbs_loop_kernel") or {}
     traffic = tr.get("bytes_per_launch")
+    # the counters come from a committed profile of an EARLIER run of this command: say how far
+    # that run's kernel time is from the one just measured, so that stale traffic shows
+    prof_ms = tr.get("profiled_avg_ms")
+    stale = (abs(prof_ms - avg_loop_ms) / avg_loop_ms > 0.05) if prof_ms else None
     r = {"bound": "hbm" if residency == "stream" else "latency", "kernel": "gibbs_loop_kernel",
          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": traffic, "traffic_source": tr.get("source"),
+         "profiled_kernel": tr.get("kernel"), "profiled_avg_ms": prof_ms, "traffic_stale": stale,
          "algorithmic_bytes_per_launch": alg_bytes,
          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
          "loop_ms_per_launch": avg_loop_ms, "us_per_iteration": us_it, "residency": residency}
@@ -391,6 +464,26 @@ def roofline_entry(st, avg_loop_ms, alg_bytes, N, K, T):
                      "steps of one iteration (draw -> residual pass -> wave/group/cross-CU sums -> "
                      "sigma2), see DESIGN.md 4.1")
     return r
+
+
+def residual_roofline(rc4):
+    """residual_rss_kernel at C4 (N = 200 000, K = 64, f32: 52 MB per pass) in the shape of the
+    `roofline` block: live HIP-event time per launch, counter traffic from the committed profile,
+    and how far that profile's kernel time is from the live one."""
+    tr = profiled_traffic("residual_rss_kernel<float, 2, 1>") or {}
+    ms = rc4["ms_per_pass"]
+    prof_ms = tr.get("profiled_avg_ms")
+    traffic = tr.get("bytes_per_launch")
+    return {"bound": "hbm", "kernel": "residual_rss_kernel<float, 2, 1>",
+            "workload": "C4: N_obs=200000, K=64, f32 storage, one coefficient vector per pass",
+            "achieved": rc4["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": rc4["frac_of_8TBs"], "ms_per_launch": ms,
+            "algorithmic_bytes_per_launch": rc4["bytes_per_pass"],
+            "traffic": traffic, "traffic_source": tr.get("source"),
+            "traffic_over_algorithmic": (traffic / rc4["bytes_per_pass"]) if traffic else None,
+            "profiled_kernel": tr.get("kernel"), "profiled_avg_ms": prof_ms,
+            "traffic_stale": (abs(prof_ms - ms) / ms > 0.05) if prof_ms else None,
+            "served_from": rc4["served_from"], "note": rc4["note"]}
 
 
 def extras(ctx, torch, dev, local_rank, N, K, T):

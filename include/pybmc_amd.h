@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PYBMC_AMD_ABI_VERSION 3
+#define PYBMC_AMD_ABI_VERSION 4
 
 typedef struct bmc_ctx bmc_ctx;
 
@@ -202,13 +202,24 @@ int bmc_simplex_run(bmc_ctx* ctx, const double* Vt_hat, int32_t n_models, const 
  * [n_q][n_points].  Coverage (optional, truth != NULL): hits[c] counts the points with
  * sorted[cov_lo[c]] <= truth <= sorted[cov_hi[c]]; n_q, n_cov <= 64; n_draws <= 16384.
  * rndm_m_out (optional) is [n_points][n_draws]: the reference's (n_draws, n_points)
- * array in Fortran order. */
+ * array in Fortran order (bmc_predict_draws returns it C-ordered). */
 int bmc_predict(bmc_ctx* ctx, const double* preds, int64_t n_points, int32_t n_models,
                 const double* theta, int32_t n_draws, int32_t k, const double* Vt_hat,
                 int rng_mode, uint64_t seed, const double* noise,
                 const int32_t* q_index, const double* q_gamma, int32_t n_q,
                 const double* truth, const int32_t* cov_lo, const int32_t* cov_hi,
                 int32_t n_cov, double* rndm_m_out, double* bands_out, int64_t* cov_hits_out);
+
+/* The draws of the LAST bmc_predict on this context, in the layout the caller wants (they stay
+ * on the device until the next bmc_predict or bmc_destroy, so a caller that asked bmc_predict for
+ * bands / coverage only can still fetch them afterwards):
+ *   BMC_DRAWS_BY_POINT  out[n_points][n_draws]   the device layout
+ *   BMC_DRAWS_BY_DRAW   out[n_draws][n_points]   a C-ordered (n_draws, n_points) array: exactly
+ *                       what rndm_m_random_calculator returns, pybmc/sampling_utils.py:77
+ *                       (transposed on the device, one contiguous copy back).
+ * BMC_ESTATE when no bmc_predict has run on this context. */
+enum { BMC_DRAWS_BY_POINT = 0, BMC_DRAWS_BY_DRAW = 1 };
+int bmc_predict_draws(bmc_ctx* ctx, double* out, int layout);
 
 /* HIP-event times of the LAST bmc_predict on this context (any pointer may be NULL):
  * h2d_ms the host->device copies of its inputs, gemm_ms the weight + MFMA GEMM(+noise)

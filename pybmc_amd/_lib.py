@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpybmc_amd.so")
 
-ABI_VERSION = 3   # PYBMC_AMD_ABI_VERSION of include/pybmc_amd.h this binding was written for
+ABI_VERSION = 4   # PYBMC_AMD_ABI_VERSION of include/pybmc_amd.h this binding was written for
 BMC_OK, BMC_EINVAL, BMC_ESINGULAR, BMC_EHIP, BMC_ENOMEM, BMC_ETIMEOUT, BMC_ESTATE = range(7)
 BMC_F64, BMC_F32 = 0, 1
 BMC_ROW_MAJOR, BMC_COL_MAJOR = 0, 1
@@ -66,6 +66,7 @@ PROTOTYPES = {
     "bmc_residual_rss_bench": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
     "bmc_gram_bench": (C.c_int, [_P, C.c_int32, _D]),
     "bmc_predict_timing": (C.c_int, [_P, _D, _D, _D, _D]),
+    "bmc_predict_draws": (C.c_int, [_P, _D, C.c_int]),
     "bmc_comm_unique_id": (C.c_int, [C.c_char_p]),
     "bmc_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_char_p]),
     "bmc_allgather": (C.c_int, [_P, _P, _P, C.c_int64]),
@@ -168,6 +169,7 @@ class Context:
         # device (BayesianModelCombination.orthogonalize(method="device")) find out whether it
         # is still there before sampling from it
         self.problem_generation = 0
+        self._last_predict = None     # (n_points, n_draws) of the last predict()
 
     # -- plumbing --------------------------------------------------------------
     def close(self):
@@ -386,10 +388,27 @@ class Context:
         return out, acc.value
 
     # -- posterior predictive --------------------------------------------------------------
+    def predict_draws(self, order="C"):
+        """The draws of the last predict() as an (n_draws, n_points) array: order "C" is the
+        reference's layout (sampling_utils.py:77; transposed on the device), order "F" a
+        Fortran-ordered array of the same shape (the device layout, no transpose)."""
+        if self._last_predict is None:
+            raise BmcError("no predict() has run on this context")
+        M, S = self._last_predict
+        if order == "C":
+            out = np.empty((S, M))
+            self._check(self._lib.bmc_predict_draws(self._h, _dptr(out), 1))
+            return out
+        out = np.empty((M, S))
+        self._check(self._lib.bmc_predict_draws(self._h, _dptr(out), 0))
+        return out.T
+
     def predict(self, preds, theta, Vt_hat, seed=0, noise=None, q=(2.5, 50, 97.5), truth=None,
-                cov_percentiles=None, want_draws=True):
+                cov_percentiles=None, want_draws=True, draws_order="C"):
         """preds (M, Km), theta (S, k+1) selected posterior rows, Vt_hat (k, Km).
-        Returns (rndm_m (S, M) Fortran-ordered or None, bands (len(q), M), coverage or None)."""
+        Returns (rndm_m (S, M) or None, bands (len(q), M), coverage or None).  rndm_m is
+        C-ordered like the reference's (draws_order="C", default) or Fortran-ordered
+        (draws_order="F": the device layout, a point's draws contiguous)."""
         preds = np.ascontiguousarray(preds, dtype=np.float64)
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         Vt_hat = np.ascontiguousarray(Vt_hat, dtype=np.float64)
@@ -407,7 +426,6 @@ class Context:
             lo, hi = coverage_plan(S, cov_percentiles)
             n_cov = len(lo)
             hits = np.zeros(n_cov, dtype=np.int64)
-        draws = np.empty((M, S)) if want_draws else None
         nz = None
         if noise is not None:
             nz = np.ascontiguousarray(noise, dtype=np.float64)
@@ -419,10 +437,11 @@ class Context:
             BMC_RNG_REPLAY if nz is not None else BMC_RNG_DEVICE, int(seed) & (2 ** 64 - 1),
             _dptr(nz), qi.ctypes.data_as(i32p), _dptr(qg), len(q), _dptr(tr),
             lo.ctypes.data_as(i32p) if lo is not None else None,
-            hi.ctypes.data_as(i32p) if hi is not None else None, n_cov, _dptr(draws),
+            hi.ctypes.data_as(i32p) if hi is not None else None, n_cov, None,
             _dptr(bands), hits.ctypes.data_as(C.POINTER(C.c_int64)) if hits is not None else None))
+        self._last_predict = (M, S)
         cov = None if hits is None else [int(h) / M * 100 for h in hits]
-        return (draws.T if draws is not None else None), bands, cov
+        return (self.predict_draws(draws_order) if want_draws else None), bands, cov
 
     # -- variates -----------------------------------------------------------------------
     def rng_fill(self, seed, n_normal=0, shape=1.0, n_gamma=0):

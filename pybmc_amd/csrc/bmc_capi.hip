@@ -61,7 +61,9 @@ struct bmc_ctx {
     // run buffers
     DevBuf xi, gam, uout, samples, gran, status, seeds, dbg, placement;
     // predictive buffers
-    DevBuf pPreds, pTheta, pVt, pWt, pSig, pR, pNoise, pAux, pBands;
+    DevBuf pPreds, pTheta, pVt, pWt, pSig, pR, pRT, pNoise, pAux, pBands;
+    int64_t pM = 0;                        // last bmc_predict: points, draws, padded draws
+    int32_t pS = 0, pS_pad = 0;
     DevBuf sVt, sStep, sUnif, sOut, sCnt;
     DevBuf oFc, oMu, oW, oOut;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -699,7 +701,7 @@ void bmc_destroy(bmc_ctx* c) {
                       &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef, &c->ticket,
                       &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
                       &c->seeds, &c->dbg, &c->placement, &c->pPreds, &c->pTheta, &c->pVt,
-                      &c->pWt, &c->pSig, &c->pR, &c->pNoise, &c->pAux, &c->pBands, &c->sVt,
+                      &c->pWt, &c->pSig, &c->pR, &c->pRT, &c->pNoise, &c->pAux, &c->pBands, &c->sVt,
                       &c->sStep, &c->sUnif, &c->sOut, &c->sCnt, &c->oFc, &c->oMu, &c->oW, &c->oOut})
         release(*b);
     for (auto& e : c->ev)
@@ -1310,6 +1312,7 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
         if (cov_lo[i] < 0 || cov_lo[i] >= S || cov_hi[i] < 0 || cov_hi[i] >= S)
             return fail(c, BMC_EINVAL, "coverage index out of range");
     HIPCHK(c, hipSetDevice(c->device));
+    c->pM = 0;   // (no draws to fetch until this call has produced them)
     PredictArgs a;
     a.M = M; a.Km = Km; a.k = k; a.S = S;
     a.S_pad = (S + 63) / 64 * 64;
@@ -1386,6 +1389,32 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->predict_ms[2] = ms;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[3])); c->predict_ms[3] = ms;
     }
+    c->pM = M;
+    c->pS = S;
+    c->pS_pad = a.S_pad;
+    return BMC_OK;
+}
+
+int bmc_predict_draws(bmc_ctx* c, double* out, int layout) {
+    if (!c) return BMC_EINVAL;
+    if (!out) return fail(c, BMC_EINVAL, "out must not be NULL");
+    if (layout != BMC_DRAWS_BY_POINT && layout != BMC_DRAWS_BY_DRAW)
+        return fail(c, BMC_EINVAL, "layout must be 0 (by point) or 1 (by draw)");
+    if (c->pM < 1 || !c->pR.p) return fail(c, BMC_ESTATE, "no bmc_predict has run on this context");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t M = c->pM;
+    const int32_t S = c->pS, S_pad = c->pS_pad;
+    if (layout == BMC_DRAWS_BY_POINT) {
+        HIPCHK(c, hipMemcpy2DAsync(out, (size_t)S * 8, c->pR.p, (size_t)S_pad * 8, (size_t)S * 8,
+                                   (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        int rc;
+        if ((rc = ensure(c, c->pRT, (size_t)S * M * 8))) return rc;
+        HIPCHK(c, launch_transpose_draws((const double*)c->pR.p, M, S, S_pad, (double*)c->pRT.p,
+                                         c->stream));
+        HIPCHK(c, hipMemcpyAsync(out, c->pRT.p, (size_t)S * M * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return BMC_OK;
 }
 
@@ -1400,6 +1429,7 @@ int bmc_predict_timing(bmc_ctx* c, double* h2d_ms, double* gemm_ms, double* orde
 }
 
 // ---- pooling over GPUs: RCCL, loaded on first use --------------------------------------
+extern "C++" {
 namespace {
 struct Rccl {
     void* h = nullptr;
@@ -1411,25 +1441,55 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 // One RCCL per process: the copy already in the process (torch loads its own, same soname)
-// wins; otherwise the loader's search path, then the ROCm install.
-const Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.h ? &r : nullptr;
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so"})
-        if (!r.h) r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-        if (!r.h) r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.h) return nullptr;
+// wins; otherwise the loader's search path, then the ROCm install.  BMC_RCCL_SONAME (tests
+// only) replaces the candidate list, so that a failing load can be exercised.
+// The table is built ONCE, by a function-local static (C++11: thread-safe, so two host threads
+// that drive two contexts cannot see it half filled); the loader's error text is taken right
+// after the failing dlopen / dlsym -- dlerror() clears itself when read -- and kept.
+struct RcclLoad {
+    Rccl r;
+    std::string err;
+};
+RcclLoad load_rccl() {
+    RcclLoad L;
+    Rccl& r = L.r;
+    std::vector<std::string> names;
+    if (const char* forced = std::getenv("BMC_RCCL_SONAME")) names = {forced};
+    else names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const std::string& name : names)
+        if (!r.h) r.h = dlopen(name.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    for (const std::string& name : names)
+        if (!r.h) {
+            (void)dlerror();
+            r.h = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (!r.h) {
+                const char* e = dlerror();
+                L.err = e ? e : (name + ": dlopen failed");
+            }
+        }
+    if (!r.h) {
+        if (L.err.empty()) L.err = "librccl.so.1 not found";
+        return L;
+    }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
     r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) {
         r.h = nullptr;
-    return r.h ? &r : nullptr;
+        L.err = "RCCL symbols missing (ncclGetUniqueId / ncclCommInitRank / ncclAllGather / "
+                "ncclCommDestroy / ncclGetErrorString)";
+    }
+    return L;
+}
+const RcclLoad& rccl_state() {
+    static const RcclLoad L = load_rccl();
+    return L;
+}
+const Rccl* rccl() {
+    const RcclLoad& L = rccl_state();
+    return L.r.h ? &L.r : nullptr;
 }
 #define RCCLCHK(ctx, R, expr)                                                          \
     do {                                                                               \
@@ -1438,6 +1498,7 @@ const Rccl* rccl() {
             return fail(ctx, BMC_EHIP, std::string(#expr) + ": " + (R)->GetErrorString(r__)); \
     } while (0)
 }  // namespace
+}  // extern "C++"
 
 int bmc_comm_unique_id(char id_out[BMC_COMM_ID_BYTES]) {
     static_assert(BMC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
@@ -1468,8 +1529,7 @@ int bmc_comm_init(bmc_ctx* c, int32_t world, int32_t rank, const char id[BMC_COM
     if (!id || world < 1 || rank < 0 || rank >= world)
         return fail(c, BMC_EINVAL, "need world >= 1, 0 <= rank < world and an id");
     const Rccl* R = rccl();
-    if (!R) return fail(c, BMC_EHIP, std::string("librccl.so.1 could not be loaded: ") +
-                                         (dlerror() ? dlerror() : "symbols missing"));
+    if (!R) return fail(c, BMC_EHIP, "RCCL could not be loaded: " + rccl_state().err);
     HIPCHK(c, hipSetDevice(c->device));
     bmc_comm_destroy(c);
     ncclUniqueId uid;

@@ -114,6 +114,9 @@ struct PredictArgs {
     hipEvent_t ev_mid = nullptr;  // recorded between the GEMM and the order statistics (or NULL)
 };
 hipError_t launch_predict(const PredictArgs& a, hipStream_t s);
+// out[s][p] = R[p][s]: the draws as the reference's C-ordered (n_draws, n_points) array
+hipError_t launch_transpose_draws(const double* R, int64_t M, int32_t S, int32_t S_pad, double* out,
+                                  hipStream_t s);
 
 // ---- the persistent Gibbs loop ------------------------------------------------
 struct GibbsArgs {

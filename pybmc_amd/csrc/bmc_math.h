@@ -11,7 +11,7 @@
 #include <string.h>
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__) 
 #define BMC_HD __host__ __device__ inline
 #else
 #define BMC_HD inline

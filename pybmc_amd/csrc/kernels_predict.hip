@@ -430,6 +430,43 @@ __global__ __launch_bounds__(SEL_THREADS, VPT > 24 ? 2 : 4) void predict_select_
     if (my_hits) atomicAdd(&hits[tid - 64], my_hits);
 }
 
+// ----------------------------------------------------------- draws in the reference's layout
+// R is [M][S_pad] (a point's draws contiguous: what the order statistics read).  The reference
+// returns rndm_m as a C-ordered (S, M) array (sampling_utils.py:77); this transposes on the
+// device, through LDS in 64 x 64 tiles (row stride 65 doubles: conflict-free both ways), so that
+// the copy back is one contiguous block in the caller's layout.
+__global__ __launch_bounds__(256) void transpose_draws_kernel(const double* __restrict__ R, int64_t M,
+                                                              int32_t S, int32_t S_pad,
+                                                              double* __restrict__ out) {
+    __shared__ double tile[64][65];
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int32_t s0 = (int32_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t p = p0 + r;
+        const int32_t sd = s0 + tx;
+        tile[r][tx] = (p < M && sd < S) ? R[p * S_pad + sd] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int32_t sd = s0 + r;
+        const int64_t p = p0 + tx;
+        if (sd < S && p < M) out[(int64_t)sd * M + p] = tile[tx][r];
+    }
+}
+
+hipError_t launch_transpose_draws(const double* R, int64_t M, int32_t S, int32_t S_pad, double* out,
+                                  hipStream_t s) {
+    const uint64_t gx = (uint64_t)((M + 63) / 64), gy = (uint64_t)((S + 63) / 64);
+    if (gx == 0 || gy == 0) return hipSuccess;
+    if (gx > 0x7fffffffull || gy > 65535ull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_draws_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, R, M,
+                       S, S_pad, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
     {
         const int64_t total = (int64_t)a.S_pad * a.Km_pad;

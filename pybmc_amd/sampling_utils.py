@@ -14,7 +14,7 @@ def rndm_m_random_calculator(filtered_model_predictions, samples, Vt_hat, *, see
     (reference sampling_utils.py:40-84).
 
     Returns ``(rndm_m, [lower, median, upper])`` with ``rndm_m`` of shape
-    ``(10000, n_points)`` (Fortran-ordered: the draws of one point are contiguous).  Needs at least 10000 posterior samples, like the
+    ``(10000, n_points)`` (C-ordered, like the reference's: sampling_utils.py:77).  Needs at least 10000 posterior samples, like the
     reference (``ValueError`` otherwise, :57).  The reference's side effect of
     re-seeding numpy's global stream (:54, quirk Q2) is not reproduced.
     """

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_the_header():
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
     lib = _lib.load_library()
-    assert lib.bmc_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.bmc_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_the_header():

@@ -41,10 +41,20 @@ def test_t1_stepwise(name):
     st = O.chain_setup(y, Xf, prior)
     W, lam, s2i = ctx.basis()
     assert abs(s2i - st["sigma2_init"]) <= STEP_TOL * st["sigma2_init"]
+    # mean / cov of beta | sigma2 against the oracle's inv(X'X/s2 + P + 1e-6 I)
+    # (inference_utils.py:41-44).  SURVEY 8(c) T1 asks for 1e-12; an explicit inverse is only
+    # accurate to about kappa * eps relative (kappa = condition number of the matrix inverted,
+    # eps = 2.2e-16) -- on BOTH sides of the comparison -- so the bar is
+    # max(1e-12, 32 kappa eps): 1e-12 itself on the orthonormal designs train() produces
+    # (kappa ~ 1), looser only where the fixture is ill-conditioned, and by how much is printed.
+    b0, C0 = np.asarray(prior[0], float), np.asarray(prior[1], float)
+    eps = np.finfo(float).eps
     for s2 in (st["sigma2_init"], 0.37, 5.0, float(g["samples"][-1, -1] ** 2)):
         m, c = ctx.conditional_moments(s2)
         mo, co = O.conditional_moments(st, y, Xf, s2)
-        assert rel(m, mo) < 1e-10 and rel(c, co) < 1e-10           # vs inv() of the oracle
+        kappa = np.linalg.cond(Xf.T @ Xf / s2 + np.linalg.inv(C0) + 1e-6 * np.eye(len(b0)))
+        bar = max(STEP_TOL, 32 * kappa * eps)
+        assert rel(m, mo) < bar and rel(c, co) < bar, (name, s2, kappa, rel(m, mo), rel(c, co))
     betas = g["samples"][:7, :-1]
     got = ctx.residual_rss(betas)
     want = np.array([O.residual_rss(y, Xf, b) for b in betas])

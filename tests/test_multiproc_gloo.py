@@ -159,3 +159,23 @@ def test_bench_spawns_its_own_ranks():
     assert len(line["rccl"]["devices"]) == 2 and len(line["rccl"]["allgather_ms_per_rank"]) == 2
     assert line["rccl"]["allgather_bytes_per_rank"] == 1 * 8 * 4 * 8
     assert "roofline" not in line and "cpu_baseline" not in line     # nothing was measured
+
+
+def test_bench_parent_fails_fast_when_a_rank_dies():
+    """A rank that dies before the rendezvous (`--fail-rank 1`: what a missing device or an RCCL
+    init error looks like) must not leave rank 0 waiting in init_process_group until torch's
+    timeout: the parent polls every child, stops the others at once, names the failed rank with
+    the tail of its output, prints no JSON line and exits non-zero."""
+    import time
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--iters", "8", "--k", "3", "--dry-run-cpu",
+                        "--fail-rank", "1", "--rank-timeout-s", "240"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    took = time.monotonic() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert took < 120, f"the parent waited {took:.0f} s for a rank that was already dead"
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank 1 exited with status 3" in r.stderr and "--fail-rank test hook" in r.stderr
