@@ -501,17 +501,23 @@ def extras(ctx, torch, dev, local_rank, N, K, T):
         extra["chains8_one_gpu"] = {"samples_per_s": 8 * T / e8, "loop_ms": st8["loop_ms"],
                                     "groups_per_chain": st8["groups_per_chain"]}
         del out8
-        # 16 chains: two per XCD, still one launch
-        seeds16 = chain_seeds(1, list(range(16)))
-        out16 = torch.empty((16, T, K + 1), dtype=torch.float64, device=dev)
-        ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
-        t1 = time.perf_counter()
-        st16 = ctx.gibbs_run_device(16, T, seeds16, out16.data_ptr())
-        torch.cuda.synchronize()
-        e16 = time.perf_counter() - t1
-        extra["chains16_one_gpu"] = {"samples_per_s": 16 * T / e16, "loop_ms": st16["loop_ms"],
-                                     "launches": st16["launches"]}
-        del out16
+        # 16 / 32 / 64 chains: the register-resident panels of an XCD serve a bundle of 2 / 4 / 8
+        # chains per pass, one bundle per XCD, ONE launch (every chain bit-identical to its solo
+        # run: tests/test_gibbs_parity_gpu.py::test_bundles_of_chains_per_xcd)
+        for nc in (16, 32, 64):
+            seedsn = chain_seeds(1, list(range(nc)))
+            outn = torch.empty((nc, T, K + 1), dtype=torch.float64, device=dev)
+            ctx.gibbs_run_device(nc, T, seedsn, outn.data_ptr())
+            t1 = time.perf_counter()
+            stn = ctx.gibbs_run_device(nc, T, seedsn, outn.data_ptr())
+            torch.cuda.synchronize()
+            en = time.perf_counter() - t1
+            extra[f"chains{nc}_one_gpu"] = {"samples_per_s": nc * T / en, "loop_ms": stn["loop_ms"],
+                                            "us_per_iteration_all": stn["loop_ms"] * 1e3 / T,
+                                            "launches": stn["launches"],
+                                            "chains_per_pass": stn["chains_per_pass"],
+                                            "waves_per_group": stn["waves_per_group"]}
+            del outn
     except Exception as e:  # never lose the headline line
         extra["chains8_one_gpu"] = {"error": str(e)}
     try:

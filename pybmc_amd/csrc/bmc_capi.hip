@@ -468,14 +468,22 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     }
     if ((rc = check_tuning_fits(c))) return rc;
     Geometry geo = choose_geometry(c, n_chains);
-    // One-XCD register residency with more than 8 chains: chains c and c + 8 share XCD c % 8,
-    // two workgroups per CU side by side.  That needs 4 waves per SIMD (two 5-wave groups must
-    // fit whatever SIMDs their waves land on), i.e. the kernel variant held to 128 VGPRs, which
-    // exists for light shapes only.  (Three or four per XCD are not used: measured, the launch
-    // then stalls for seconds.)
-    int pack = 0;
-    if (geo.mode == 0 && geo.G > 1 && geo.nslot == chip_of(c).xcds && n_chains > geo.nslot &&
-        c->tune.groups_per_chain <= 0 && 2 * geo.waves <= 16) {
+    // One-XCD register residency with more than 8 chains.
+    // (a) 16 chains or more: the register-resident panels of an XCD's 32 groups serve a BUNDLE of
+    //     2 / 4 / 8 chains per pass (gibbs_multi_kernel, one bundle per XCD: 16 .. 64 chains in one
+    //     launch); every chain bit-identical to its solo run.
+    // (b) 9 .. 15 chains left: chains c and c + 8 share XCD c % 8, two workgroups per CU side by
+    //     side.  That needs 4 waves per SIMD (two 5-wave groups must fit whatever SIMDs their
+    //     waves land on), i.e. the kernel variant held to 128 VGPRs, which exists for light
+    //     shapes only.  (Three or four per XCD are not used: measured, the launch then stalls.)
+    const int xcds = chip_of(c).xcds;
+    const bool one_xcd_reg = geo.mode == 0 && geo.G > 1 && geo.nslot == xcds && xcds > 1 &&
+                             geo.G <= chip_of(c).cu_per_xcd && c->tune.groups_per_chain <= 0;
+    const bool xcd_bundles = one_xcd_reg && geo.ppw == 1 && c->vec == 1 && geo.G <= 32 &&
+                             c->tune.chains_per_pass != 1 &&
+                             bmc::gibbs_reg_multi_cap(c->k, c->f32 != 0, c->vec) >= 2;
+    int pack_ok = 0;
+    if (one_xcd_reg && n_chains > geo.nslot && 2 * geo.waves <= 16) {
         int32_t regs = 0;
         GibbsArgs q{};
         q.P = panels_of(c, c->Xrot.p);
@@ -488,16 +496,16 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         qo.pack = 1;
         qo.query_occupancy = &per_cu;
         if (launch_gibbs(q, c->stream) == hipSuccess && regs > 0 && regs <= 128 &&
-            launch_gibbs(qo, c->stream) == hipSuccess && per_cu >= 2) {
-            pack = 1;
-            geo.nslot *= 2;
-            geo.chains_per_launch = n_chains < geo.nslot ? n_chains : geo.nslot;
-        }
+            launch_gibbs(qo, c->stream) == hipSuccess && per_cu >= 2)
+            pack_ok = 1;
     }
+    // the most chains one launch can hold (sizes the exchange words)
+    int max_per_launch = geo.chains_per_launch;
+    if (pack_ok) max_per_launch = 2 * geo.nslot;
+    if (xcd_bundles) max_per_launch = 8 * xcds;
+    if (max_per_launch < 8) max_per_launch = 8;
     const int gran_stride = bmc::gran_slot_words(geo.G);
-    if ((rc = ensure(c, c->gran, (size_t)(geo.chains_per_launch > 8 ? geo.chains_per_launch : 8) * 3 *
-                                     gran_stride * 8)))
-        return rc;
+    if ((rc = ensure(c, c->gran, (size_t)max_per_launch * 3 * gran_stride * 8))) return rc;
     if ((rc = ensure(c, c->status, C * sizeof(int32_t)))) return rc;
     if ((rc = ensure(c, c->placement, C * sizeof(int32_t)))) return rc;
     HIPCHK(c, hipMemsetAsync(c->placement.p, 0, C * sizeof(int32_t), c->stream));
@@ -548,7 +556,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     }
     a.dbg = nullptr;
     a.query_regs = nullptr;
-    a.pack = pack;
+    a.pack = 0;
 #ifdef BMC_STAMPS
     if ((rc = ensure(c, c->dbg, 12 * sizeof(long long)))) return rc;
     HIPCHK(c, hipMemsetAsync(c->dbg.p, 0, 12 * sizeof(long long), c->stream));
@@ -556,7 +564,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
 #endif
     // chains per pass: when the panels are NOT register-resident one read of X can serve up to
     // 8 chains (one leader wave per chain); 0 = automatic, 1 = off
-    int cpp_max = 1;
+    int cpp_max = 1, waves_multi = geo.waves;
     // (register residency: only the whole-chip form, one chain bundle per launch, one panel per
     // wave; the one-XCD-per-chain form already runs 8 chains side by side)
     const bool reg_multi_ok = geo.mode == 0 && geo.nslot < 8 && geo.G > 1 && geo.ppw == 1;
@@ -567,6 +575,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         if (c->tune.chains_per_pass > 1 && c->tune.chains_per_pass < want)
             want = c->tune.chains_per_pass >= 4 ? 4 : 2;
         if (a.waves < want && c->tune.waves_per_group <= 0) a.waves = want;
+        waves_multi = a.waves;
         cpp_max = a.waves >= 8 ? 8 : a.waves >= 4 ? 4 : a.waves >= 2 ? 2 : 1;
         if (cpp_max > want) cpp_max = want;
         if (reg_multi_ok) {
@@ -591,14 +600,49 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         HIPCHK(c, launch_gibbs_gram(ga, c->stream));
         launches = 1;
     }
+    int64_t passes = 0;
     for (int c0 = 0; !gram_mode && iters > 0 && c0 < n_chains;) {
         const int left = n_chains - c0;
-        int cpp = 1;
-        while (cpp * 2 <= left && cpp * 2 <= cpp_max) cpp *= 2;
-        const int m = cpp > 1 ? cpp : (left < geo.chains_per_launch ? left : geo.chains_per_launch);
+        int cpp = 1, m, resident;
+        a.bundle_slots = 0;
+        a.pack = 0;
+        a.nslot = geo.nslot;
+        // bundles pay from 4 chains per XCD on (measured at C2, us per iteration for all chains:
+        // 16 chains 1.37 as bundles of 2 against 1.05 packed two per XCD; 32 chains 1.81 as
+        // bundles of 4 against 2 x 1.05; 64 chains 2.33 as bundles of 8); with fewer they are
+        // used when asked for (chains_per_pass = 2) or when the shape has no packed variant
+        if (xcd_bundles && left >= 2 * xcds &&
+            (left >= 4 * xcds || !pack_ok || c->tune.chains_per_pass > 1)) {
+            // one bundle per XCD: as many chains per bundle as keep all XCDs busy
+            int cap = bmc::gibbs_reg_multi_cap(K, a.P.f32 != 0, a.P.vec);
+            if (c->tune.chains_per_pass > 1 && c->tune.chains_per_pass < cap) cap = c->tune.chains_per_pass;
+            cpp = 2;
+            while (cpp * 2 <= cap && cpp * 2 * xcds <= left) cpp *= 2;
+            const int bundles = left / cpp < xcds ? left / cpp : xcds;
+            m = bundles * cpp;
+            a.bundle_slots = xcds;
+            a.waves = waves_single > cpp ? waves_single : cpp;   // a leader wave per chain
+            resident = bundles * a.G;
+            passes += (int64_t)bundles * iters;
+        } else if (cpp_max > 1 && left >= 2) {
+            while (cpp * 2 <= left && cpp * 2 <= cpp_max) cpp *= 2;
+            m = cpp;
+            a.waves = waves_multi;
+            resident = a.G;
+            passes += iters;
+        } else {
+            a.waves = waves_single;
+            if (pack_ok && left > geo.nslot) {
+                a.pack = 1;
+                a.nslot = 2 * geo.nslot;
+            }
+            const int cap = a.pack ? a.nslot : geo.chains_per_launch;
+            m = left < cap ? left : cap;
+            resident = m * a.G;
+            passes += (int64_t)m * iters;
+        }
         a.n_chains = m;
         a.chains_per_pass = cpp;
-        if (cpp == 1) a.waves = waves_single;
         if (cpp > cpp_used) cpp_used = cpp;
         if (a.waves > waves_used) waves_used = a.waves;
         a.xi = (const double*)c->xi.p + (size_t)c0 * T * K;
@@ -609,8 +653,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)m * 3 * gran_stride * 8, c->stream));
         if (gibbs_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
         if (a.G > 1 || cpp > 1)   // (a single-workgroup chain waits for nobody)
-            if ((rc = check_residency(c, a, (cpp > 1 ? 1 : m) * a.G, launch_gibbs,
-                                      "persistent Gibbs kernel")))
+            if ((rc = check_residency(c, a, resident, launch_gibbs, "persistent Gibbs kernel")))
                 return rc;
         HIPCHK(c, launch_gibbs(a, c->stream));
         ++launches;
@@ -648,7 +691,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         for (size_t i = 0; i < C; ++i) stats->xcd_local_chains += place[i] ? 1 : 0;
         stats->bytes_per_pass = ((int64_t)c->n * K + c->n) * (c->f32 ? 4 : 8);
         // a pass that serves several chains counts once
-        stats->passes = gram_mode ? 0 : cpp_used > 1 ? (int64_t)launches * iters : (int64_t)n_chains * iters;
+        stats->passes = gram_mode ? 0 : passes;
         if (gram_mode) { stats->groups_per_chain = 1; stats->waves_per_group = 1; }
     }
     for (size_t i = 0; i < C; ++i)

@@ -140,7 +140,11 @@ struct GibbsArgs {
     int32_t reg_ppw;        // panels per wave (register mode)
     int32_t nslot;          // grid = nslot x G; 8 = one slot per XCD, else = n_chains
     int32_t force_agent_scope;  // 1: never use the XCD-local exchange
-    int32_t chains_per_pass;  // > 1: gibbs_multi_kernel, one bundle of that many chains
+    int32_t chains_per_pass;  // > 1: gibbs_multi_kernel, bundles of that many chains
+    int32_t bundle_slots = 0; // gibbs_multi_kernel: 0 = ONE bundle, grid = G (a chain over the whole
+                              // chip); > 0 = grid = bundle_slots x G, bundle b = blockIdx % slots
+                              // (one bundle per XCD: chains b * cpp .. b * cpp + cpp - 1), n_chains
+                              // = bundles * chains_per_pass, unused slots leave at once
     int32_t* placement;     // [C] out: 1 = chain verified on one XCD (L2-local exchange)
     int32_t panels_per_group;  // max panels a group owns
     long long* dbg;         // diagnostic builds only (-DBMC_STAMPS); NULL otherwise

@@ -22,13 +22,15 @@ struct LdsPlan {
 // u: K doubles zero-padded to a multiple of 64 (MODE_REG reads KMAX of them);
 // aux: kernel-specific doubles (the simplex kernel keeps Vt_hat there when it fits).
 __host__ __device__ inline LdsPlan lds_plan(int K, int elem, int RP, int ppg, bool lds_resident,
-                                            int aux_doubles = 0, int u_slices = 1) {
+                                            int aux_doubles = 0, int u_slices = 1, int red_slices = 1) {
     LdsPlan L;
     const size_t kp = (size_t)((K + 63) & ~63) * sizeof(double) * (size_t)u_slices;
     size_t o = 0;
     L.u = o;   o += kp;
-    L.red = o; o += RED_DOUBLES * sizeof(double);   // one chain: [waves <= 8][64 lanes]; several
-                                                    // chains per pass: [chains <= 8][waves <= 8]
+    L.red = o; o += (size_t)RED_DOUBLES * sizeof(double) * (size_t)red_slices;
+                                                    // one chain: [waves <= 8][64 lanes]; several
+                                                    // chains per pass: [chains <= 8][waves <= 8], or
+                                                    // (lane-wise form) [chains][waves <= 8][64 lanes]
     L.ctl = o; o += 8 * sizeof(double);
     L.aux = o; o += (size_t)((aux_doubles + 1) & ~1) * sizeof(double);
     L.y = o;
@@ -308,7 +310,11 @@ struct PanelStore {
     T* ys;
     int K, G, g, npl, nw, wave, lane, keep;
 
-    __device__ __forceinline__ void init(const Panels& P, int G_, int g_, T* Xs_, T* ys_) {
+    // share_last (register residency, one panel per wave, several chains per pass): the waves
+    // past the group's last panel hold a COPY of that panel, so that its chains can be split
+    // among them (gibbs_multi_kernel) instead of one SIMD carrying two whole panels
+    __device__ __forceinline__ void init(const Panels& P, int G_, int g_, T* Xs_, T* ys_,
+                                         bool share_last = false) {
         keep = P.stream_keep;
         Xg = reinterpret_cast<const T*>(P.X);
         yg = reinterpret_cast<const T*>(P.y);
@@ -326,7 +332,8 @@ struct PanelStore {
         if constexpr (MODE == MODE_REG) {
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
-                const int q = wave + i * nw;
+                int q = wave + i * nw;
+                if (share_last && PPW == 1 && npl > 0 && q >= npl) q = npl - 1;
                 const bool have = q < npl;
                 const int64_t p = g + (int64_t)q * G;
 #pragma unroll
@@ -356,9 +363,10 @@ struct PanelStore {
     // here the address of block b's reads is made to depend (through empty asm statements that
     // emit no code) on the accumulators of block b-DEPTH, so at most DEPTH blocks of UB values of
     // u are live at a time.
+    // chains [c_lo, c_hi) only (wave-uniform): the other entries of s are left as they are
     template <int CPP>
-    __device__ __forceinline__ void partial_rss_reg_multi(const double* u, int kpad,
-                                                          double (&s)[CPP]) const {
+    __device__ __forceinline__ void partial_rss_reg_multi(const double* u, int kpad, double (&s)[CPP],
+                                                          int c_lo = 0, int c_hi = CPP) const {
         static_assert(MODE == MODE_REG, "register residency only");
         typedef const __attribute__((address_space(3))) double lds_cd;
 #ifndef BMC_REGMULTI_LDS
@@ -371,42 +379,65 @@ struct PanelStore {
         if constexpr (KMAX >= 16) {
             lds_cd* ub = (lds_cd*)u;
             constexpr int NU = (KMAX + 15) / 16;
+            // the u of several chains first (CH chains x NU registers, at most 16 doubles = 32 VGPRs:
+            // all 8 chains at 32 columns), so that ONE LDS latency is paid per CH chains instead
+            // of one per chain (stamps, 8 chains at C2: the pass took 2650 cycles for 256 FMAs)
+            constexpr int CH = (16 / NU) >= CPP ? CPP : (16 / NU);
+            static_assert(CPP % CH == 0, "chains per chunk");
+            static_for<CPP / CH>([&](auto hc) {
+                constexpr int c0 = decltype(hc)::value * CH;
+                double urow[CH][NU];
 #pragma unroll
-            for (int c = 0; c < CPP; ++c) {
-                double urow[NU];
+                for (int c = 0; c < CH; ++c)
 #pragma unroll
-                for (int r = 0; r < NU; ++r) urow[r] = ub[c * kpad + r * 16 + (lane & 15)];
+                    for (int r = 0; r < NU; ++r) urow[c][r] = ub[(c0 + c) * kpad + r * 16 + (lane & 15)];
                 // (pinned where they are loaded: the DPP statements are opaque to hipcc, which
                 // otherwise re-reads u from LDS in front of every one of them)
 #pragma unroll
-                for (int r = 0; r < NU; ++r) asm volatile("" : "+v"(urow[r]));
-                double acc[PPW][VEC][4];
+                for (int c = 0; c < CH; ++c)
 #pragma unroll
-                for (int i = 0; i < PPW; ++i)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        acc[i][v][0] = (double)yr[i][v];
-                        acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
-                    }
-                static_for<KMAX>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
+                    for (int r = 0; r < NU; ++r) asm volatile("" : "+v"(urow[c][r]));
+                auto one_chain = [&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    double acc[PPW][VEC][4];
 #pragma unroll
                     for (int i = 0; i < PPW; ++i)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v)
-                            fmac_rowbcast_neg<j % 16, (j % 16 == 0)>(acc[i][v][j % 4], urow[j / 16],
-                                                                   as_f64_in_loop(xr[i][j][v]));
-                });
-                double t = 0.0;
+                        for (int v = 0; v < VEC; ++v) {
+                            acc[i][v][0] = (double)yr[i][v];
+                            acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
+                        }
+                    static_for<KMAX>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
 #pragma unroll
-                for (int i = 0; i < PPW; ++i)
+                        for (int i = 0; i < PPW; ++i)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const double r = (acc[i][v][0] + acc[i][v][1]) + (acc[i][v][2] + acc[i][v][3]);
-                        t = fma(r, r, t);
-                    }
-                s[c] = t;
-            }
+                            for (int v = 0; v < VEC; ++v)
+                                fmac_rowbcast_neg<j % 16, (j % 16 == 0)>(acc[i][v][j % 4], urow[c][j / 16],
+                                                                       as_f64_in_loop(xr[i][j][v]));
+                    });
+                    double t = 0.0;
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const double r = (acc[i][v][0] + acc[i][v][1]) + (acc[i][v][2] + acc[i][v][3]);
+                            t = fma(r, r, t);
+                        }
+                    s[c0 + c] = t;
+                };
+                // a wave that computes every chain (the usual case) runs the chains back to back
+                // with no test between them: hipcc then overlaps the closing additions of one
+                // chain with the first FMAs of the next
+                if (c_lo == 0 && c_hi == CPP) {
+                    static_for<CH>([&](auto cc) { one_chain(cc); });
+                } else {
+                    static_for<CH>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if (c0 + c >= c_lo && c0 + c < c_hi) one_chain(cc);
+                    });
+                }
+            });
             return;
         }
 #endif
@@ -424,6 +455,7 @@ struct PanelStore {
         for (int d = 0; d < DEPTH; ++d) tok[d] = 0;
 #pragma unroll
         for (int c = 0; c < CPP; ++c) {
+            if (c < c_lo || c >= c_hi) continue;
             double acc[PPW][VEC][4];
 #pragma unroll
             for (int i = 0; i < PPW; ++i)
@@ -795,6 +827,39 @@ __device__ __forceinline__ double group_allreduce_multi(const double (&s)[CPP], 
     GSTAMP(4);
     return exchange_sum<(CPP >= 4)>(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane, epoch,
                                     local, ok STAMP_ARGS, idle);
+}
+
+// The same for register residency with one row per lane, in the lane-wise form of
+// group_allreduce<LANEWISE>: every wave leaves its 64 lane partials of every chain in LDS
+// ([chain][wave][lane], rows of absent waves stay 0), and leader c adds the 8 rows of its chain
+// lane by lane in the fixed tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and runs ONE wave-level sum
+// -- instead of CPP wave sums in every wave in front of the barrier.  Operation for operation
+// the reduction of the single-chain kernel, so a chain's bits do not depend on whether it
+// shares its pass.
+// `row` = the local panel the wave computed (its own index, or the shared last panel's), and
+// [c_lo, c_hi) the chains it computed it for: rows are indexed by PANEL, as in the single-chain
+// kernel, whichever wave did the work.
+template <int CPP, int TEAMS = -1, typename F = NoIdleWork>
+__device__ __forceinline__ double group_allreduce_multi_lanewise(const double (&s)[CPP], double* red,
+                                                                 int row, int c_lo, int c_hi,
+                                                                 gu64* gp_chain0, size_t chain_stride,
+                                                                 int G, int g, int wave, int lane,
+                                                                 unsigned epoch, bool local,
+                                                                 bool& ok STAMP_PARAMS, F idle = F()) {
+#pragma unroll
+    for (int c = 0; c < CPP; ++c)
+        if (c >= c_lo && c < c_hi) red[(c * 8 + row) * 64 + lane] = s[c];
+    GSTAMP(3);
+    __syncthreads();
+    ok = true;
+    if (wave >= CPP) return 0.0;
+    const double* r = red + (size_t)wave * 512 + lane;
+    const double r0 = r[0], r1 = r[64], r2 = r[128], r3 = r[192];
+    const double r4 = r[256], r5 = r[320], r6 = r[384], r7 = r[448];
+    const double t = wave_sum(((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)));
+    GSTAMP(4);
+    return exchange_sum<(CPP >= 4), F, TEAMS>(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane,
+                                             epoch, local, ok STAMP_ARGS, idle);
 }
 
 }  // namespace bmc

@@ -324,25 +324,38 @@ void gibbs_loop_kernel(GibbsArgs a) {
 // state, and -- in group 0 -- its recorded draws); all waves accumulate CPP partial sums per
 // panel column.  Arithmetic per chain is that of gibbs_loop_kernel, operation for operation.
 // ======================================================================================
-template <typename T, int VEC, int MODE, int CPP, int KMAX = 0, int PPW = 0>
+// SLOTTED: one bundle per XCD slot (bundle_slots > 0), which implies G <= 32: the one-level
+// exchange is known at compile time and the two-level code leaves the loop.
+template <typename T, int VEC, int MODE, int CPP, int KMAX = 0, int PPW = 0, bool SLOTTED = false>
 __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
     // lane-chunks of 64 columns: register residency means K <= 64, so one chunk is known at
     // compile time (fewer live registers and no dead branches in the leader's serial phase)
     constexpr int KCH = (MODE == MODE_REG) ? 1 : MAX_KCH;
+    // register residency, one row per lane: the lane-wise group sum of the single-chain kernel
+    // (group_allreduce<LANEWISE>), so that a chain is bit-identical to its solo run
+    constexpr bool LANEWISE = (MODE == MODE_REG && VEC == 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = a.P.k, G = a.G;
-    int g = blockIdx.x;                   // one bundle of CPP chains per launch
+    // one bundle of CPP chains over the whole grid, or (bundle_slots > 0) one bundle per slot:
+    // blocks b and b + slots share an XCD (observed), bundle b % slots runs chains
+    // [CPP (b % slots), CPP (b % slots) + CPP) on the G groups b / slots
+    const int slots = SLOTTED ? a.bundle_slots : 1;
+    const int bundle = (int)(blockIdx.x % (unsigned)slots);
+    int g = (int)(blockIdx.x / (unsigned)slots);
+    if (bundle * CPP >= a.n_chains) return;   // unused slot: the whole workgroup leaves
+    const int chain0 = bundle * CPP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
     const int64_t T_it = a.iters;
+    gu64* gran0 = a.gran + (size_t)chain0 * 3 * a.gran_stride;   // this bundle's first chain
 #ifndef BMC_NO_XCD_REMAP
     // team j on XCD j whichever XCD the launch starts on (see gibbs_loop_kernel)
-    if (G > 32 && (G & 7) == 0) {
+    if (!SLOTTED && G > 32 && (G & 7) == 0) {
         __shared__ int rot_c;
         if (wave == 0) {
-            const int c = detect_rotation(a.gran + (size_t)2 * a.gran_stride + 256, G, g, lane);
+            const int c = detect_rotation(gran0 + (size_t)2 * a.gran_stride + 256, G, g, lane);
             if (lane == 0) rot_c = c;
         }
         __syncthreads();
@@ -350,36 +363,56 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     }
 #endif
 
-    const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, MODE == MODE_LDS, 0, CPP);
+    const LdsPlan L = lds_plan(K, (int)sizeof(T), RP, a.panels_per_group, MODE == MODE_LDS, 0, CPP,
+                               LANEWISE ? CPP : 1);
     double* u_lds = reinterpret_cast<double*>(smem + L.u);   // [CPP][kpad]
-    double* red = reinterpret_cast<double*>(smem + L.red);   // [CPP][8]
+    double* red = reinterpret_cast<double*>(smem + L.red);   // [CPP][8] or [CPP][8][64]
     double* ctl = reinterpret_cast<double*>(smem + L.ctl);   // [1] abort, [2] local
     const int kpad = (K + 63) & ~63;
     for (int j = tid; j < kpad * CPP; j += blockDim.x) u_lds[j] = 0.0;
-    for (int j = tid; j < RED_DOUBLES; j += blockDim.x) red[j] = 0.0;   // rows / slots of absent waves stay 0
+    // rows / slots of absent waves stay 0
+    for (int j = tid; j < RED_DOUBLES * (LANEWISE ? CPP : 1); j += blockDim.x) red[j] = 0.0;
     if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; }
 
     PanelStore<T, VEC, MODE, KMAX, PPW> store;
-    store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y));
+    store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y), LANEWISE);
+    // Which (panel, chains) this wave computes.  Lane-wise form (one panel per wave): wave w < npl
+    // owns local panel w; the waves past the last panel hold a copy of it and split its CPP chains
+    // with its owner -- C2: 5 panels on a CU's 4 SIMDs, 8 waves: 8 + 2 (panel, chain) units per
+    // SIMD instead of 16 on the SIMD that carries panels 0 and 4.
+    int c_lo = 0, c_hi = CPP, row = wave;
+    if constexpr (LANEWISE) {
+        const int npl = store.npl;
+        if (npl == 0) {
+            c_hi = 0;
+        } else if (wave >= npl - 1) {
+            const int sharers = nw - npl + 1, r = wave - (npl - 1);
+            c_lo = r * CPP / sharers;
+            c_hi = (r + 1) * CPP / sharers;
+            row = npl - 1;
+        }
+    }
 
     const size_t chain_stride = (size_t)3 * a.gran_stride;
     if (wave == 0) {
-        const int place = detect_placement(a.gran + 2 * a.gran_stride, G, g, lane);
+        const int place = detect_placement(gran0 + 2 * a.gran_stride, G, g, lane);
         if (lane == 0) {
-            if (place < 0) { ctl[1] = 1.0; a.status[0] = 1; }
+            if (place < 0) { ctl[1] = 1.0; a.status[chain0] = 1; }
             ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
         }
     }
     __syncthreads();
     const bool local = ctl[2] != 0.0;
-    if (g == 0 && tid < CPP) a.placement[tid] = local ? 1 : 0;
+    if (g == 0 && tid < CPP) a.placement[chain0 + tid] = local ? 1 : 0;
 
-    const bool leader = wave < CPP;
-    const int chain = leader ? wave : 0;
+    // (a slotted bundle of 8 chains runs 8 waves -- the host sees to it -- so every wave leads)
+    const bool leader = (SLOTTED && CPP == 8) ? true : wave < CPP;
+    const int chain_l = leader ? wave : 0;            // within the bundle
+    const int chain = chain0 + chain_l;               // within the launch
     const double* xi = a.xi + (int64_t)chain * T_it * K;
     const double* gam = a.gam + (int64_t)chain * T_it;
     double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
-    double* u_mine = u_lds + (size_t)chain * kpad;
+    double* u_mine = u_lds + (size_t)chain_l * kpad;
 
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see gibbs_loop_kernel
     double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = BMC_SQRT_OF(a.sigma2_init);
@@ -426,7 +459,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         double s[CPP];
 #pragma unroll
         for (int c = 0; c < CPP; ++c) s[c] = 0.0;
-        if constexpr (MODE == MODE_REG) store.template partial_rss_reg_multi<CPP>(u_lds, kpad, s);
+        if constexpr (MODE == MODE_REG) store.template partial_rss_reg_multi<CPP>(u_lds, kpad, s, c_lo, c_hi);
         for (int q = store.wave; MODE != MODE_REG && q < store.npl; q += store.nw) {
             if constexpr (MODE == MODE_LDS) {
                 panel_rss_multi<T, VEC, CPP>(store.Xs + (size_t)q * K * RP + lane * VEC,
@@ -447,14 +480,21 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
             asm volatile("" : "+v"(abort_late) : "v"(s[CPP - 1]));
             if (__builtin_amdgcn_readfirstlane(__double2hiint(abort_late)) != 0) break;
         }
-        // next iteration's variates, behind the residual pass (see gibbs_loop_kernel)
-        if (leader && t + 1 < T_it) {
+        // next iteration's variates, behind the residual pass (see gibbs_loop_kernel).  Loaded by
+        // every wave, at clamped indices, with no branch around the loads: under `if (leader &&
+        // t + 1 < T)` hipcc loads into a temporary and copies it into the loop-carried register
+        // at the join, with an s_waitcnt vmcnt(0) right here -- a global-load latency on every
+        // wave's way to the group barrier (stamps, 64 chains at C2: 630 cycles between the pass
+        // and the barrier).  A wave that leads no chain reads the first chain's variates and
+        // never uses them.
+        {
+            const int64_t tn = t + 1 < T_it ? t + 1 : t;
 #pragma unroll
             for (int ch = 0; ch < KCH; ++ch) {
                 const int j = ch * 64 + lane;
-                if (ch * 64 < K && j < K) xi_next[ch] = xi[(t + 1) * K + j];
+                xi_next[ch] = xi[tn * K + (j < K ? j : K - 1)];
             }
-            gam_next = gam[t + 1];
+            gam_next = gam[tn];
         }
         bool got;
         // group 0's leaders record their chain (row t, and sigma of the previous row) between
@@ -470,9 +510,15 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                 if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
             }
         };
-        const double rss = group_allreduce_multi<CPP>(s, red, a.gran + (size_t)(t & 1) * a.gran_stride,
-                                                      chain_stride, G, g, wave, nw, lane, epoch,
-                                                      local, got STAMP_ARGS, record);
+        double rss;
+        if constexpr (LANEWISE)
+            rss = group_allreduce_multi_lanewise<CPP, (SLOTTED ? 0 : -1)>(
+                s, red, row, c_lo, c_hi, gran0 + (size_t)(t & 1) * a.gran_stride, chain_stride, G, g,
+                wave, lane, epoch, local, got STAMP_ARGS, record);
+        else
+            rss = group_allreduce_multi<CPP>(s, red, gran0 + (size_t)(t & 1) * a.gran_stride,
+                                             chain_stride, G, g, wave, nw, lane, epoch, local,
+                                             got STAMP_ARGS, record);
         if (leader) {
             if (!got) {
                 if (lane == 0) { ctl[1] = 1.0; a.status[chain] = 1; }
@@ -746,8 +792,11 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
 }
 
 size_t gibbs_lds_bytes(const GibbsArgs& a) {
+    const int cpp = a.chains_per_pass > 1 ? a.chains_per_pass : 1;
+    // (several chains per pass in register residency with one row per lane: lane-wise group sum)
+    const bool lanewise_multi = cpp > 1 && a.mode == MODE_REG && a.P.vec == 1;
     return lds_plan(a.P.k, a.P.f32 ? 4 : 8, 64 * a.P.vec, a.panels_per_group, a.mode == MODE_LDS, 0,
-                    a.chains_per_pass > 1 ? a.chains_per_pass : 1).total;
+                    cpp, lanewise_multi ? cpp : 1).total;
 }
 size_t simplex_lds_bytes(const SimplexArgs& a) {
     return lds_plan(a.P.k, a.P.f32 ? 4 : 8, 64 * a.P.vec, a.panels_per_group, a.mode == MODE_LDS,
@@ -926,14 +975,23 @@ template <typename T, int VEC, int KMAX>
 static hipError_t launch_multi_reg_k(const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
 #define BMC_MR(C)                                                                            \
-    return launch_or_query((const void*)gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1>,        \
-                           dim3(a.G), dim3(64 * a.waves), lds, s, a, a.query_occupancy)
+    do {                                                                                         \
+        if constexpr (VEC == 1) {                                                                \
+            if (a.bundle_slots > 0)                                                              \
+                return launch_or_query(                                                          \
+                    (const void*)gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1, true>,           \
+                    dim3(a.bundle_slots * a.G), dim3(64 * a.waves), lds, s, a, a.query_occupancy); \
+        }                                                                                        \
+        if (a.bundle_slots > 0) return hipErrorInvalidValue;                                     \
+        return launch_or_query((const void*)gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 1>,    \
+                               dim3(a.G), dim3(64 * a.waves), lds, s, a, a.query_occupancy);     \
+    } while (0)
     // only the combinations that fit the 256-VGPR budget without spilling are built
     constexpr int CMAX = reg_multi_cap(KMAX, sizeof(T) == 4, VEC);
     switch (a.chains_per_pass) {
-        case 2: if constexpr (CMAX >= 2) { BMC_MR(2); } break;
-        case 4: if constexpr (CMAX >= 4) { BMC_MR(4); } break;
-        case 8: if constexpr (CMAX >= 8) { BMC_MR(8); } break;
+        case 2: if constexpr (CMAX >= 2) BMC_MR(2); break;
+        case 4: if constexpr (CMAX >= 4) BMC_MR(4); break;
+        case 8: if constexpr (CMAX >= 8) BMC_MR(8); break;
     }
 #undef BMC_MR
     return hipErrorInvalidValue;
@@ -961,8 +1019,11 @@ static hipError_t launch_multi_reg(const GibbsArgs& a, hipStream_t s) {
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
     if (a.chains_per_pass > 1) {
         if (a.query_regs) return hipErrorInvalidValue;
-        // one bundle of chains_per_pass chains; needs a leader wave per chain
-        if (!geometry_ok(a) || a.waves < a.chains_per_pass || a.n_chains != a.chains_per_pass)
+        // bundles of chains_per_pass chains (one, or one per slot); a leader wave per chain
+        if (!geometry_ok(a) || a.waves < a.chains_per_pass || a.n_chains < a.chains_per_pass ||
+            a.n_chains % a.chains_per_pass != 0 || a.bundle_slots < 0 ||
+            a.n_chains / a.chains_per_pass > (a.bundle_slots > 0 ? a.bundle_slots : 1) ||
+            (a.bundle_slots > 0 && (a.G > 32 || a.mode != MODE_REG)))
             return hipErrorInvalidValue;
         if (a.mode == MODE_REG)
             return a.P.f32 ? launch_multi_reg<float>(a, s) : launch_multi_reg<double>(a, s);

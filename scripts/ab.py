@@ -33,6 +33,8 @@ CASES = {   # name: (problem factory, dtype, chains, iterations)
     "c2": (lambda: synth(10000, 32), np.float64, 1, 20000),
     "c2x8": (lambda: synth(10000, 32), np.float64, 8, 20000),
     "c2x16": (lambda: synth(10000, 32), np.float64, 16, 20000),
+    "c2x32": (lambda: synth(10000, 32), np.float64, 32, 20000),
+    "c2x64": (lambda: synth(10000, 32), np.float64, 64, 10000),
     "c4": (lambda: dense(200000, 64, np.float32), np.float32, 1, 3000),
     "c4x8": (lambda: dense(200000, 64, np.float32), np.float32, 8, 1000),
     "c5": (lambda: dense(50000, 256, np.float64), np.float64, 1, 1500),

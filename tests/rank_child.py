@@ -55,10 +55,18 @@ def main():
         out = torch.empty((len(mine), a.iters, a.k + 1), dtype=torch.float64, device=dev)
         dist.barrier()           # both ranks launch at about the same time: real co-residency
         stats = None
-        for _ in range(a.runs):
+        first = None
+        unstable = 0             # runs whose output differs from this rank's first run
+        for r in range(a.runs):
             if mine:
                 stats = ctx.gibbs_run_device(len(mine), a.iters, chain_seeds(a.base_seed, mine),
                                              out.data_ptr())
+                if a.runs > 1:
+                    cur = out.cpu()
+                    if first is None:
+                        first = cur
+                    elif not torch.equal(cur, first):
+                        unstable += 1
         host = out.cpu()         # gloo pools host tensors
         pooled = pool_samples(host, a.n_chains)
         info = [None] * a.world
@@ -66,7 +74,9 @@ def main():
                                       "groups": stats["groups_per_chain"] if stats else 0,
                                       "waves": stats["waves_per_group"] if stats else 0,
                                       "launches": stats["launches"] if stats else 0,
-                                      "loop_ms": stats["loop_ms"] if stats else 0.0})
+                                      "loop_ms": stats["loop_ms"] if stats else 0.0,
+                                      "xcd_local": stats["xcd_local_chains"] if stats else 0,
+                                      "unstable_runs": unstable})
         if a.rank == 0:
             np.save(a.out, pooled.numpy())
             import json

@@ -473,25 +473,62 @@ def test_several_chains_per_pass(n, k, res, nch):
         assert np.abs(out[c] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
 
 
-def test_two_chains_per_xcd_when_more_than_eight_chains():
-    """One-XCD register residency with more than 8 chains: chains c and c + 8 share XCD c (two
-    workgroups per CU side by side), 16 chains per launch.  Every chain is bit-identical to the
-    same seed run alone."""
-    ctx = gpu_ctx()
-    rng = np.random.default_rng(7)
-    n, k = 10000, 32
+def c2_like_problem(ctx, n=10000, k=32, seed=7):
+    rng = np.random.default_rng(seed)
     X = rng.standard_normal((n, k)) / np.sqrt(n)
     y = X @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)
     ctx.set_problem(y, X)
     ctx.set_prior(np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+
+
+def test_two_chains_per_xcd_when_more_than_eight_chains():
+    """One-XCD register residency with 9 .. 15 chains: chains c and c + 8 share XCD c (two
+    workgroups per CU side by side, the 128-VGPR variant of the kernel).  Every chain is
+    bit-identical to the same seed run alone."""
+    ctx = gpu_ctx()
+    c2_like_problem(ctx)
     T = 400
-    seeds = np.arange(19) + 100
-    out, st = ctx.gibbs_run(19, T, seeds=seeds)
-    assert st["residency"] == 1 and st["groups_per_chain"] <= 32
-    assert st["launches"] == 2 and st["xcd_local_chains"] in (0, 19)
-    for c in (0, 7, 8, 15, 16, 18):
+    seeds = np.arange(13) + 100
+    out, st = ctx.gibbs_run(13, T, seeds=seeds)
+    assert st["residency"] == 1 and st["groups_per_chain"] <= 32 and st["chains_per_pass"] == 1
+    assert st["launches"] == 1 and st["xcd_local_chains"] in (0, 13)
+    for c in (0, 7, 8, 12):
         solo, _ = ctx.gibbs_run(1, T, seeds=seeds[c:c + 1])
         assert np.array_equal(out[c], solo[0])
+
+
+@pytest.mark.parametrize("nch,cpp,launches,ask", [(64, 8, 1, 0), (19, 2, 2, 2), (37, 4, 2, 0),
+                                                  (130, 8, 3, 0), (40, 4, 2, 4)])
+def test_bundles_of_chains_per_xcd(nch, cpp, launches, ask):
+    """One-XCD register residency with 16 chains or more (the headline size): the resident
+    panels of an XCD's 32 workgroups serve a bundle of 2 / 4 / 8 chains per pass, one bundle per
+    XCD, 16 .. 64 chains per launch (gibbs_multi_kernel with bundle slots); what is left over
+    runs as before.  Bundles of 2 are slower than the two-per-XCD packing and only used when
+    asked for (`ask` = bmc_tuning.chains_per_pass).  Every chain -- first and last of a bundle, of a launch, and the left-overs
+    -- is BIT-identical to the same seed run alone: the lane-wise group sum of the bundle kernel
+    is operation for operation that of the single-chain kernel."""
+    ctx = gpu_ctx()
+    c2_like_problem(ctx)
+    T = 300
+    seeds = np.arange(nch) + 1000
+    ctx.set_tuning(chains_per_pass=ask)
+    out, st = ctx.gibbs_run(nch, T, seeds=seeds)
+    ctx.set_tuning()
+    assert st["residency"] == 1 and st["groups_per_chain"] == 32
+    assert st["chains_per_pass"] == cpp and st["launches"] == launches, st
+    assert st["xcd_local_chains"] in (0, nch)
+    assert st["passes"] < nch * T               # a pass that serves a bundle counts once
+    probe = sorted({0, 1, cpp - 1, cpp, 8 * cpp - 1, min(8 * cpp, nch - 1), nch // 2, nch - 2, nch - 1})
+    for c in probe:
+        solo, st1 = ctx.gibbs_run(1, T, seeds=seeds[c:c + 1])
+        assert st1["chains_per_pass"] == 1
+        assert np.array_equal(out[c], solo[0]), c
+    # chains_per_pass = 1 switches the bundles off: the 16-per-launch packing of round 2
+    ctx.set_tuning(chains_per_pass=1)
+    off, st_off = ctx.gibbs_run(min(nch, 20), T, seeds=seeds[:20])
+    ctx.set_tuning()
+    assert st_off["chains_per_pass"] == 1
+    assert np.array_equal(off, out[:min(nch, 20)])
 
 
 @pytest.mark.parametrize("n,k,dt,nch", [(100000, 32, np.float64, 8), (120000, 7, np.float64, 5),
@@ -519,6 +556,9 @@ def test_several_chains_per_pass_register_residency(n, k, dt, nch):
     assert st["residency"] == 1 and st["chains_per_pass"] in (2, 4, 8)
     assert st["launches"] < st1["launches"]
     assert np.abs(shared - solo).max() < 1e-11 * max(1.0, np.abs(solo).max())
+    if dt == np.float64:
+        # one row per lane: the shared pass reduces lane-wise exactly like the single-chain kernel
+        assert np.array_equal(shared, solo)
     if dt == np.float64:
         Xd, yd = X.astype(np.float64), y.astype(np.float64)
         st_o = O.chain_setup(yd, Xd, prior)

@@ -62,6 +62,17 @@ def run_ranks(tmp_path, world, n_chains, iters, n, k, cu_limit, runs=1):
     return np.load(out), info
 
 
+def describe_difference(a, b):
+    """Which chains differ, from which iteration on and by how much (assertion message)."""
+    out = []
+    for c in range(a.shape[0]):
+        d = np.abs(a[c] - b[c]).max(axis=1)
+        nz = np.nonzero(d)[0]
+        out.append(f"chain {c}: " + ("equal" if len(nz) == 0 else
+                                     f"{len(nz)} rows differ, first t={nz[0]} |d|={d[nz[0]]:.3e}, max {d.max():.3e}"))
+    return "; ".join(out)
+
+
 def single_process(n_chains, iters, n, k):
     ctx = gpu_ctx()
     p = synth_problem(n, k + 1, k, seed=0)
@@ -78,7 +89,7 @@ def test_two_ranks_single_workgroup_chains(tmp_path, n_chains):
     pooled, info = run_ranks(tmp_path, 2, n_chains, iters, n, k, cu_limit=128)
     ref, st = single_process(n_chains, iters, n, k)
     assert pooled.shape == ref.shape == (n_chains, iters, k + 1)
-    assert np.array_equal(pooled, ref)
+    assert np.array_equal(pooled, ref), describe_difference(pooled, ref)
     assert [i["chains"] for i in info] == [chain_block(n_chains, 2, r) for r in range(2)]
 
 
@@ -93,6 +104,19 @@ def test_two_ranks_at_the_headline_size(tmp_path, n_chains):
     assert st["groups_per_chain"] == 32
     assert all(i["groups"] == 32 and i["waves"] == st["waves_per_group"] for i in info), info
     assert pooled.shape == ref.shape == (n_chains, iters, k + 1)
-    assert np.array_equal(pooled, ref)
+    if not np.array_equal(pooled, ref):
+        # say which side moved: the single-process run repeated, and on a fresh context
+        ref2, _ = single_process(n_chains, iters, n, k)
+        from pybmc_amd import _lib
+        fresh = _lib.Context(0)
+        p = synth_problem(n, k + 1, k, seed=0)
+        fresh.set_problem(p["y"], p["X"])
+        fresh.set_prior(*p["prior"])
+        ref3, _ = fresh.gibbs_run(n_chains, iters, seeds=chain_seeds(11, list(range(n_chains))))
+        fresh.close()
+        pytest.fail("pooled != single process: " + describe_difference(pooled, ref)
+                    + " | single process repeated: " + describe_difference(ref2, ref)
+                    + " | fresh context: " + describe_difference(ref3, ref)
+                    + " | pooled vs fresh: " + describe_difference(pooled, ref3))
     # and the pooled posterior is the posterior: sigma on the generating 0.1
     assert abs(pooled[:, iters // 5:, -1].mean() - 0.1) < 0.01
