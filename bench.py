@@ -486,6 +486,94 @@ def residual_roofline(rc4):
             "served_from": rc4["served_from"], "note": rc4["note"]}
 
 
+def e2e_surface(local_rank, iters=50000):
+    """Wall clock of the REFERENCE SURFACE: BayesianModelCombination.orthogonalize -> train
+    (50 000 iterations) -> predict2 -> evaluate, the way docs/usage.md drives the reference
+    (pybmc/bmc.py:79-376), with everything a user pays for: host SVD / pandas, uploads, the host
+    K x K algebra of set_prior, the loop, the copy back of the samples and of rndm_m.  Beside
+    each, the pieces timed on their own through the same context, and the reference's figures
+    measured in the build container (other CPU, read as orders of
+    magnitude)."""
+    import contextlib
+    import io
+
+    import pandas as pd
+
+    from pybmc_amd import BayesianModelCombination, _lib
+
+    def tick():
+        return time.perf_counter()
+
+    out = {}
+    for tag, n, km, k in (("c1_629x4_k3", 629, 4, 3), ("c2_shaped_10000x33_k32", 10000, 33, 32)):
+        rng = np.random.Generator(np.random.PCG64(0))
+        truth = rng.standard_normal(n) * 2 + 5
+        cols = {"N": np.arange(n), "Z": np.arange(n) % 97, "truth": truth}
+        models = [f"m{j}" for j in range(km)]
+        for j, name in enumerate(models):
+            cols[name] = truth + rng.normal(0.1 * j, 1.0, n) + rng.normal(0, 0.5, n)
+        df = pd.DataFrame(cols)
+        bmc = BayesianModelCombination(models, {"P": df}, "truth", device=local_rank)
+        e = {}
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):       # ([INFO] default-value prints, as the reference)
+            for rep in range(2):                     # second pass timed: buffers exist, clocks up
+                t0 = tick(); bmc.orthogonalize("P", df, k); e["orthogonalize_s"] = tick() - t0
+                t0 = tick(); bmc.train({"iterations": iters}); e["train_s"] = tick() - t0
+                t0 = tick(); rndm_m, lo, med, up = bmc.predict2("P"); e["predict2_s"] = tick() - t0
+                t0 = tick(); cov = bmc.evaluate(); e["evaluate_s"] = tick() - t0
+        e["total_s"] = e["orthogonalize_s"] + e["train_s"] + e["predict2_s"] + e["evaluate_s"]
+        e["train_samples_per_s"] = iters / e["train_s"]
+        st = bmc.last_stats
+        e["train_device_ms"] = {"variates": st["rng_ms"], "loop": st["loop_ms"], "unrotate": st["post_ms"]}
+        e["rndm_m"] = {"shape": list(rndm_m.shape), "c_contiguous": bool(rndm_m.flags.c_contiguous),
+                       "MB": rndm_m.nbytes / 1e6}
+        assert len(cov) == 21 and med.shape[0] == n
+        # the pieces of train() on their own
+        ctx = _lib.default_context(local_rank)
+        y, X = bmc.centered_experiment_train, bmc.U_hat
+        t0 = tick(); ctx.set_problem(y, X); up_s = tick() - t0
+        t0 = tick(); ctx.set_prior(np.zeros(k), np.diag(bmc.S_hat ** 2), 1.0, 0.02); pr_s = tick() - t0
+        t0 = tick(); smp, st2 = ctx.gibbs_run(1, iters, seeds=[3]); run_s = tick() - t0
+        e["train_split_s"] = {"upload_panelize_gram": up_s, "set_prior_host_algebra_rotate": pr_s,
+                              "variates_loop_unrotate_copyback": run_s,
+                              "of_which_loop": st2["loop_ms"] * 1e-3,
+                              "copyback_MB": smp.nbytes / 1e6,
+                              "python_and_prints": max(0.0, e["train_s"] - up_s - pr_s - run_s)}
+        out[tag] = e
+    out["c1_629x4_k3"]["reference_cpu"] = ("train() 8 117 samples/s at N=629, K_models=15, kept 3 "
+                                            "(BASELINE.md section 2, 8 vCPU Xeon)")
+    out["c2_shaped_10000x33_k32"]["reference_cpu"] = (
+        "gibbs_sampler 1.1-1.6 k samples/s at N=10 000, k=31; orthogonalize (full-matrices SVD) 6.6 s; "
+        "predict2 3.7 s at M=2 000 (BASELINE.md section 2)")
+    # the C5 posterior predictive through the context: bands + coverage only, and with the
+    # 4 GB of draws returned in the reference's layout (C-ordered (10000, M): device transpose +
+    # one contiguous copy into pageable numpy memory)
+    rng = np.random.Generator(np.random.PCG64(55))
+    Mp, Kmp, kp, Sp = 50000, 257, 256, 10000
+    preds = rng.standard_normal((Mp, Kmp))
+    Vt_hat = rng.standard_normal((kp, Kmp)) * 0.05
+    theta = np.column_stack([rng.standard_normal((Sp, kp)) * 0.1, rng.uniform(0.05, 0.15, Sp)])
+    cp = _lib.Context(local_rank)
+    e = {}
+    for want, key in ((False, "bands_and_coverage_only_s"), (True, "with_rndm_m_returned_s")):
+        for rep in range(2):
+            t0 = tick()
+            r = cp.predict(preds, theta, Vt_hat, seed=9, truth=preds.mean(1),
+                           cov_percentiles=list(range(0, 101, 5)), want_draws=want)
+            e[key] = tick() - t0
+        if want:
+            e["rndm_m"] = {"shape": list(r[0].shape), "c_contiguous": bool(r[0].flags.c_contiguous),
+                           "GB": r[0].nbytes / 1e9}
+        del r
+    tm = cp.predict_timing()
+    e["device_ms"] = tm
+    e["reference_cpu"] = "rndm_m_random_calculator 11.7 s at M=5 000, K=32 (BASELINE.md section 2)"
+    out["c5_predictive_50000x257"] = e
+    cp.close()
+    return out
+
+
 def extras(ctx, torch, dev, local_rank, N, K, T):
     from pybmc_amd import _lib
     from pybmc_amd.chains import chain_seeds
@@ -660,6 +748,10 @@ def extras(ctx, torch, dev, local_rank, N, K, T):
         cp.close()
     except Exception as e:
         extra["predict_c5"] = {"error": str(e)}
+    try:
+        extra["e2e"] = e2e_surface(local_rank)
+    except Exception as e:
+        extra["e2e"] = {"error": repr(e)}
     return extra
 
 

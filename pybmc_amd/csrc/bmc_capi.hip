@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pybmc_amd.h"
@@ -61,13 +62,16 @@ struct bmc_ctx {
     // run buffers
     DevBuf xi, gam, uout, samples, gran, status, seeds, dbg, placement;
     // predictive buffers
-    DevBuf pPreds, pTheta, pVt, pWt, pSig, pR, pRT, pNoise, pAux, pBands;
+    DevBuf pPreds, pPad, pTheta, pVt, pWt, pSig, pR, pRT, pNoise, pAux, pBands;
     int64_t pM = 0;                        // last bmc_predict: points, draws, padded draws
     int32_t pS = 0, pS_pad = 0;
     DevBuf sVt, sStep, sUnif, sOut, sCnt;
     DevBuf oFc, oMu, oW, oOut;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double predict_ms[4] = {0, 0, 0, 0};   // last bmc_predict: h2d, gemm, order statistics, device
+    // pinned staging for results that go back to pageable host memory (copy_to_host)
+    void* hstage[2] = {nullptr, nullptr};
+    hipEvent_t hev[2] = {nullptr, nullptr};
     // pooling over GPUs (bmc_comm_*): RCCL communicator bound to this context's device
     ncclComm_t comm = nullptr;
     int32_t comm_world = 0, comm_rank = 0;
@@ -106,6 +110,92 @@ void release(DevBuf& b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+}
+
+// Device -> caller-owned (pageable) host memory.  A plain hipMemcpy into fresh numpy memory
+// pins the destination pages first, which costs far more than the transfer for the sizes that
+// matter here (13.2 MB of samples at C2: 29 ms, against 0.3 ms of DMA -- bench.py extra.e2e).
+// Instead: DMA into two pinned staging blocks in turn and copy out of one with the CPU while the
+// next is in flight; large results are copied out by several host threads (one thread moves
+// ~8 GB/s into untouched pages, the 4 GB of C5's rndm_m would take 0.5 s).
+constexpr size_t HSTAGE_BYTES = (size_t)32 << 20;
+void host_copy(char* dst, const char* src, size_t bytes) {
+    const size_t MT_MIN = (size_t)8 << 20;
+    unsigned nt = bytes >= MT_MIN ? 4 : 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && nt > hw) nt = hw;
+    if (nt <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+    for (unsigned i = 0; i < nt; ++i) {
+        const size_t off = (size_t)i * per;
+        if (off >= bytes) break;
+        const size_t n = bytes - off < per ? bytes - off : per;
+        th.emplace_back([=] { std::memcpy(dst + off, src + off, n); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// rows of `row_bytes` taken every `src_pitch` bytes on the device, written densely to `dst`
+// (src_pitch == row_bytes: one contiguous block of row_bytes * rows).  Blocks until the data is
+// in `dst`.
+int copy_to_host(bmc_ctx* c, void* dst, const void* src_dev, size_t row_bytes, size_t src_pitch,
+                 size_t rows) {
+    if (row_bytes == 0 || rows == 0) return BMC_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (!c->hstage[i] && hipHostMalloc(&c->hstage[i], HSTAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+            c->hstage[i] = nullptr;
+            (void)hipGetLastError();
+        }
+        if (!c->hev[i] && hipEventCreateWithFlags(&c->hev[i], hipEventDisableTiming) != hipSuccess)
+            c->hev[i] = nullptr;
+    }
+    const bool dense = src_pitch == row_bytes;
+    const bool staged = c->hstage[0] && c->hstage[1] && c->hev[0] && c->hev[1] &&
+                        (dense || row_bytes <= HSTAGE_BYTES);
+    if (!staged) {   // (no pinned memory to be had: the plain route)
+        HIPCHK(c, hipMemcpy2DAsync(dst, row_bytes, src_dev, src_pitch, row_bytes, rows,
+                                   hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BMC_OK;
+    }
+    // pieces: dense -> byte ranges of at most one staging block; pitched -> whole rows
+    const size_t total = dense ? row_bytes * rows : rows;          // bytes, or rows
+    const size_t per = dense ? HSTAGE_BYTES : HSTAGE_BYTES / row_bytes;
+    const size_t unit = dense ? 1 : row_bytes;                     // host bytes per unit of `total`
+    char* out = (char*)dst;
+    size_t issued = 0;
+    size_t p_n[2] = {0, 0}, p_off[2] = {0, 0};
+    bool pending[2] = {false, false};
+    int next = 0;   // slot of the next transfer; the other slot holds the older pending one
+    while (issued < total || pending[0] || pending[1]) {
+        while (issued < total && !pending[next]) {
+            const size_t n = total - issued < per ? total - issued : per;
+            if (dense)
+                HIPCHK(c, hipMemcpyAsync(c->hstage[next], (const char*)src_dev + issued, n,
+                                         hipMemcpyDeviceToHost, c->stream));
+            else
+                HIPCHK(c, hipMemcpy2DAsync(c->hstage[next], row_bytes,
+                                           (const char*)src_dev + issued * src_pitch, src_pitch,
+                                           row_bytes, n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->hev[next], c->stream));
+            pending[next] = true;
+            p_n[next] = n;
+            p_off[next] = issued * unit;
+            issued += n;
+            next ^= 1;
+        }
+        // drain the older pending block (`next` if both are pending, else the one that is)
+        const int o = pending[next] ? next : next ^ 1;
+        HIPCHK(c, hipEventSynchronize(c->hev[o]));
+        host_copy(out + p_off[o], (const char*)c->hstage[o], p_n[o] * unit);
+        pending[o] = false;
+        next = o;
+    }
+    return BMC_OK;
 }
 
 Panels panels_of(const bmc_ctx* c, const void* X) {
@@ -669,10 +759,10 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
                              c->stream));
     HIPCHK(c, hipMemcpyAsync(place.data(), c->placement.p, C * sizeof(int32_t),
                              hipMemcpyDeviceToHost, c->stream));
-    if (samples_host && iters > 0)
-        HIPCHK(c, hipMemcpyAsync(samples_host, d_samples, C * T * (K + 1) * 8,
-                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (samples_host && iters > 0)
+        if ((rc = copy_to_host(c, samples_host, d_samples, C * T * (K + 1) * 8, C * T * (K + 1) * 8, 1)))
+            return rc;
     if (stats) {
         float ms = 0;
         std::memset(stats, 0, sizeof(*stats));
@@ -744,11 +834,15 @@ void bmc_destroy(bmc_ctx* c) {
                       &c->gramScratch, &c->gramOut, &c->rssPartial, &c->rssOut, &c->coef, &c->ticket,
                       &c->stage, &c->xi, &c->gam, &c->uout, &c->samples, &c->gran, &c->status,
                       &c->seeds, &c->dbg, &c->placement, &c->pPreds, &c->pTheta, &c->pVt,
-                      &c->pWt, &c->pSig, &c->pR, &c->pRT, &c->pNoise, &c->pAux, &c->pBands, &c->sVt,
+                      &c->pPad, &c->pWt, &c->pSig, &c->pR, &c->pRT, &c->pNoise, &c->pAux, &c->pBands, &c->sVt,
                       &c->sStep, &c->sUnif, &c->sOut, &c->sCnt, &c->oFc, &c->oMu, &c->oW, &c->oOut})
         release(*b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (c->hev[i]) (void)hipEventDestroy(c->hev[i]);
+        if (c->hstage[i]) (void)hipHostFree(c->hstage[i]);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1360,14 +1454,17 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
     a.M = M; a.Km = Km; a.k = k; a.S = S;
     a.S_pad = (S + 63) / 64 * 64;
     a.Km_pad = (Km + 3) / 4 * 4;
+    a.M_pad = (M + 63) / 64 * 64;
     a.seed = seed;
     a.n_q = n_q; a.n_cov = n_cov;
     const size_t szP = (size_t)M * Km * 8, szT = (size_t)S * (k + 1) * 8, szV = (size_t)k * Km * 8;
     int rc;
     if ((rc = ensure(c, c->pPreds, szP)) || (rc = ensure(c, c->pTheta, szT)) ||
-        (rc = ensure(c, c->pVt, szV)) || (rc = ensure(c, c->pWt, (size_t)a.S_pad * a.Km_pad * 8)) ||
+        (rc = ensure(c, c->pVt, szV)) ||
+        (rc = ensure(c, c->pWt, ((size_t)a.S_pad * a.Km_pad + 16) * 8)) ||
+        (rc = ensure(c, c->pPad, ((size_t)a.M_pad * a.Km_pad + 16) * 8)) ||
         (rc = ensure(c, c->pSig, (size_t)a.S_pad * 8)) ||
-        (rc = ensure(c, c->pR, (size_t)M * a.S_pad * 8)) ||
+        (rc = ensure(c, c->pR, (size_t)a.M_pad * a.S_pad * 8)) ||
         (rc = ensure(c, c->pBands, (size_t)(n_q > 0 ? n_q : 1) * M * 8)))
         return rc;
     // aux block: q_index[64] i32 | cov_lo[64] | cov_hi[64] | q_gamma[64] f64 | hits[64] u64 |
@@ -1400,6 +1497,7 @@ int bmc_predict(bmc_ctx* c, const double* preds, int64_t M, int32_t Km, const do
     a.theta = (const double*)c->pTheta.p;
     a.Vt = (const double*)c->pVt.p;
     a.Wt = (double*)c->pWt.p;
+    a.P = (double*)c->pPad.p;
     a.sig = (double*)c->pSig.p;
     a.R = (double*)c->pR.p;
     a.q_index = (const int32_t*)(aux + offQ);
@@ -1447,18 +1545,14 @@ int bmc_predict_draws(bmc_ctx* c, double* out, int layout) {
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t M = c->pM;
     const int32_t S = c->pS, S_pad = c->pS_pad;
-    if (layout == BMC_DRAWS_BY_POINT) {
-        HIPCHK(c, hipMemcpy2DAsync(out, (size_t)S * 8, c->pR.p, (size_t)S_pad * 8, (size_t)S * 8,
-                                   (size_t)M, hipMemcpyDeviceToHost, c->stream));
-    } else {
-        int rc;
-        if ((rc = ensure(c, c->pRT, (size_t)S * M * 8))) return rc;
-        HIPCHK(c, launch_transpose_draws((const double*)c->pR.p, M, S, S_pad, (double*)c->pRT.p,
-                                         c->stream));
-        HIPCHK(c, hipMemcpyAsync(out, c->pRT.p, (size_t)S * M * 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return BMC_OK;
+    int rc;
+    if (layout == BMC_DRAWS_BY_POINT)
+        return copy_to_host(c, out, c->pR.p, (size_t)S * 8, (size_t)S_pad * 8, (size_t)M);
+    if ((rc = ensure(c, c->pRT, (size_t)S * M * 8))) return rc;
+    HIPCHK(c, launch_transpose_draws((const double*)c->pR.p, M, S, S_pad, (double*)c->pRT.p,
+                                     c->stream));
+    // (rows of one draw: M doubles each, dense)
+    return copy_to_host(c, out, c->pRT.p, (size_t)M * 8, (size_t)M * 8, (size_t)S);
 }
 
 int bmc_predict_timing(bmc_ctx* c, double* h2d_ms, double* gemm_ms, double* orderstat_ms,

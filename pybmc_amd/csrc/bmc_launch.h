@@ -93,13 +93,15 @@ struct PredictArgs {
     int64_t M;
     int32_t Km, k, S;      // models, kept components, draws
     int32_t S_pad, Km_pad; // multiples of 64 and 4
+    int64_t M_pad;         // points rounded up to whole 64-point tiles
+    double* P;             // [M_pad][Km_pad] + 16 doubles of slack: preds zero-padded (scratch)
     const double* theta;   // [S][k+1] selected posterior rows
     const double* Vt;      // [k][Km]
-    double* Wt;            // [S_pad][Km_pad] scratch
+    double* Wt;            // [S_pad][Km_pad] + 16 doubles of slack, scratch
     double* sig;           // [S_pad] scratch
     uint64_t seed;
     const double* noise_replay;  // [S][M] or NULL (device generator)
-    double* R;             // [M][S_pad]
+    double* R;             // [M_pad][S_pad]
     const int32_t* q_index;
     const double* q_gamma;
     int32_t n_q;

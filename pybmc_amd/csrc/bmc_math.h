@@ -37,16 +37,20 @@ BMC_HD double log_normal_arg(double x) {
     ix = ((uint64_t)hx << 32) | (ix & 0xffffffffull);
     double m;
     memcpy(&m, &ix, 8);
+    // (the polynomials are written with explicit fma: one instruction per coefficient on the
+    // GPU -- the library is compiled with -ffp-contract=off -- and the same, exactly rounded,
+    // operation in the CPU build of this text, so both produce the same bits)
     const double f = m - 1.0;
-    const double hfsq = 0.5 * f * f;
+    const double hfsq = (0.5 * f) * f;
     const double s = f / (2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double dk = (double)k;
-    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+    const double lo = fma(s, hfsq + R, dk * ln2_lo);
+    return fma(dk, ln2_hi, f - (hfsq - lo));
 }
 
 // sin(2 pi u) and cos(2 pi u) for 0 <= u <= 1: 4u = q + r with q the nearest integer (exact),
@@ -64,13 +68,13 @@ BMC_HD void sincos_2pi(double u, double& sn, double& cs) {
     const double x = r * 1.57079632679489661923;    // |x| <= pi/4
     const double z = x * x;
     const double v = z * x;
-    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    const double ksin = x + v * (S1 + z * rs);
+    const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    const double ksin = fma(v, fma(z, rs, S1), x);
     const double w = z * z;
-    const double rc = z * (C1 + z * (C2 + z * C3)) + w * w * (C4 + z * (C5 + z * C6));
+    const double rc = fma(w * w, fma(z, fma(z, C6, C5), C4), z * fma(z, fma(z, C3, C2), C1));
     const double hz = 0.5 * z;
     const double w1 = 1.0 - hz;
-    const double kcos = w1 + (((1.0 - w1) - hz) + z * rc);
+    const double kcos = w1 + fma(z, rc, (1.0 - w1) - hz);
     const int iq = (int)q & 3;
     const double a = (iq & 1) ? kcos : ksin;        // |sin| of the quadrant
     const double b = (iq & 1) ? ksin : kcos;

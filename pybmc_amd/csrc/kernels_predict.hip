@@ -17,32 +17,55 @@ namespace bmc {
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 // ------------------------------------------------------------------ weights
+// Wt[s][m] = sum_i theta[s][i] Vt[i][m] + 1/Km.  One workgroup = 64 model columns x 16 draws:
+// lane = column (the Vt row segment is one coalesced 512-byte read per i), each of the 4 waves
+// keeps 4 draws, whose theta[s][i] are wave-uniform (scalar loads).  Per output the order of
+// operations is fixed: four chains over i mod 4, then ((v0 + v1) + (v2 + v3)) + 1/Km.
+// (Round 2 computed one output per thread, 256 dependent loads each: 0.49 ms at C5 for 1.3 GFLOP.)
+constexpr int PW_S = 16;
 __global__ __launch_bounds__(256) void predict_weights_kernel(
     const double* __restrict__ theta, const double* __restrict__ Vt, int32_t S, int32_t k,
     int32_t Km, int32_t S_pad, int32_t Km_pad, double* __restrict__ Wt,
     double* __restrict__ sig) {
-    const int64_t total = (int64_t)S_pad * Km_pad;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x * 64 + lane;
+    const int sb = blockIdx.y * PW_S + wave * 4;      // this wave's 4 draws
+    const bool mok = m < Km;
+    const int mc = mok ? m : Km - 1;                  // clamped: loads stay in bounds
+    double v[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[r][c] = 0.0;
+    const double* th[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) th[r] = theta + (int64_t)(sb + r < S ? sb + r : S - 1) * (k + 1);
+    int i = 0;
+    for (; i + 3 < k; i += 4) {
+        double x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = Vt[(size_t)(i + c) * Km + mc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[r][c] = fma(th[r][i + c], x[c], v[r][c]);
+    }
+    for (; i < k; ++i) {
+        const double x = Vt[(size_t)i * Km + mc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r][0] = fma(th[r][i], x, v[r][0]);
+    }
     const double w0 = 1.0 / (double)Km;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int32_t s = (int32_t)(e / Km_pad), m = (int32_t)(e - (int64_t)s * Km_pad);
-        double v = 0.0;
-        if (s < S && m < Km) {
-            const double* th = theta + (int64_t)s * (k + 1);
-            // four independent chains (a single one is k dependent FMAs: latency-bound)
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-            int i = 0;
-            for (; i + 3 < k; i += 4) {
-                v0 = fma(th[i], Vt[(size_t)i * Km + m], v0);
-                v1 = fma(th[i + 1], Vt[(size_t)(i + 1) * Km + m], v1);
-                v2 = fma(th[i + 2], Vt[(size_t)(i + 2) * Km + m], v2);
-                v3 = fma(th[i + 3], Vt[(size_t)(i + 3) * Km + m], v3);
-            }
-            for (; i < k; ++i) v0 = fma(th[i], Vt[(size_t)i * Km + m], v0);
-            v = ((v0 + v1) + (v2 + v3)) + w0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sd = sb + r;
+        if (sd < S_pad) {
+            if (m < Km_pad)
+                Wt[(int64_t)sd * Km_pad + m] =
+                    (sd < S && mok) ? ((v[r][0] + v[r][1]) + (v[r][2] + v[r][3])) + w0 : 0.0;
+            if (m == 0) sig[sd] = sd < S ? theta[(int64_t)sd * (k + 1) + k] : 0.0;
         }
-        Wt[e] = v;
-        if (m == 0) sig[s] = s < S ? theta[(int64_t)s * (k + 1) + k] : 0.0;
     }
 }
 
@@ -55,6 +78,19 @@ __global__ __launch_bounds__(256) void predict_weights_kernel(
 // consecutive k = dword banks 36 r + 2 k (+0, +1) mod 64, all distinct -> conflict-free.
 // MFMA maps (f64 form, cdna guide section 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
 // D: col = l&15, row = (l>>4) + 4*reg.
+//
+// What bounds it (round 3, scripts/micro/mfma_valu_overlap.hip): on gfx950 a saturated
+// v_mfma_f64_16x16x4_f64 stream (64 cycles per instruction and SIMD = the 78.6 TF of the
+// datasheet, reached with two MFMA waves per SIMD) does NOT overlap with vector-ALU work of
+// other waves on the same SIMD -- f64, f32 and integer alike: 2 MFMA + 2 VALU waves per SIMD take
+// the SUM of their times, to the percent.  The kernel's time is therefore
+// (MFMA instructions x 64 + VALU instructions x ~4) cycles per SIMD, and the lever is the VALU
+// instruction count: round 2 executed 3 830 vector instructions per wave beside its 272 MFMAs
+// (accumulators copied VGPR <-> AGPR around every slab, 64-bit index products and bounds tests in
+// every fetch, un-fused polynomial arithmetic in the Box-Muller transform).  Now: operands
+// padded to whole tiles (no bounds tests anywhere in the kernel), per-thread base pointers
+// advanced by a constant, MFMAs in VGPR form (-amdgpu-mfma-vgpr-form), the last slab trimmed to
+// the k-steps that exist, fused polynomials (bmc_math.h).
 constexpr int PG_KT = 16, PG_LD = 18, PG_TM = 64;
 #ifndef BMC_PG_ST
 #define BMC_PG_ST 16
@@ -68,9 +104,23 @@ __device__ __forceinline__ void pg_noise(uint64_t e, uint32_t k0, uint32_t k1, d
     box_muller_pair(u53_open0(r.x, r.y), u53_open0(r.z, r.w), z0, z1);   // bmc_math.h
 }
 
+// preds [M][Km] -> P [M_pad][Km_pad], zero in the padding (rows of whole tiles, columns of whole
+// k-steps): the GEMM then reads and writes without a single bounds test
+__global__ __launch_bounds__(256) void predict_pad_kernel(const double* __restrict__ preds, int64_t M,
+                                                          int32_t Km, int64_t M_pad, int32_t Km_pad,
+                                                          double* __restrict__ P) {
+    const int64_t total = M_pad * Km_pad;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t p = e / Km_pad;
+        const int32_t m = (int32_t)(e - p * Km_pad);
+        P[e] = (p < M && m < Km) ? preds[p * Km + m] : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void predict_gemm_kernel(
-    const double* __restrict__ preds, int64_t M, int32_t Km, const double* __restrict__ Wt,
-    const double* __restrict__ sig, int32_t S, int32_t S_pad, int32_t Km_pad, uint64_t seed,
+    const double* __restrict__ P, const double* __restrict__ Wt, const double* __restrict__ sig,
+    int64_t M, int32_t S, int32_t S_pad, int32_t Km_pad, uint64_t seed,
     const double* __restrict__ noise_replay, double* __restrict__ R, uint32_t ntx, uint32_t nty,
     uint32_t nsx) {
     __shared__ double As[2 * PG_TM * PG_LD];
@@ -98,69 +148,105 @@ __global__ __launch_bounds__(256) void predict_gemm_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    // staging: element e = tid + 256 q of a 64 x 16 slab -> row e / 16, column e % 16
-    const int sr = tid >> 4, sc = tid & 15;    // rows sr + 16 q
+    // staging: element e = tid + 256 q of a 64 x 16 slab -> row sr + 16 q, column sc.  One base
+    // pointer per operand and thread, rows 16 Km_pad elements apart, slabs 16 elements apart.
+    // (A slab's columns past Km_pad belong to the next row or to the 16 doubles of slack behind
+    // the buffers: staged, never multiplied -- the last slab runs only the k-steps that exist.)
+    const int sr = tid >> 4, sc = tid & 15;
+    // (a wave-uniform base per operand, advanced by the slab, plus four 32-bit byte offsets per
+    // thread that never change: the loads take the scalar-base form and the loop computes no
+    // address at all -- written as p[q * rstep + m0] hipcc redid the 64-bit products every slab)
+    const char* abase = reinterpret_cast<const char*>(P + p0 * Km_pad);
+    const char* bbase = reinterpret_cast<const char*>(Wt + (int64_t)s0 * Km_pad);
+    uint32_t voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) voff[q] = (uint32_t)(((sr + 16 * q) * Km_pad + sc) * 8);
     double ra[4], rb[4];
     auto fetch = [&](int m0) {
-        const int m = m0 + sc;
+        const char* ab = abase + (size_t)m0 * 8;
+        const char* bb = bbase + (size_t)m0 * 8;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = sr + 16 * q;
-            const int64_t p = p0 + r;
-            ra[q] = (p < M && m < Km) ? preds[p * Km + m] : 0.0;
-            rb[q] = (m < Km_pad) ? Wt[(int64_t)(s0 + r) * Km_pad + m] : 0.0;
+            ra[q] = *reinterpret_cast<const double*>(ab + voff[q]);
+            rb[q] = *reinterpret_cast<const double*>(bb + voff[q]);
         }
     };
+    double* as_w = As + sr * PG_LD + sc;
+    double* bs_w = Bs + sr * PG_LD + sc;
     auto stash = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = sr + 16 * q;
-            As[(buf * PG_TM + r) * PG_LD + sc] = ra[q];
-            Bs[(buf * PG_TM + r) * PG_LD + sc] = rb[q];
+            as_w[(buf * PG_TM + 16 * q) * PG_LD] = ra[q];
+            bs_w[(buf * PG_TM + 16 * q) * PG_LD] = rb[q];
         }
     };
+    const double* a_r = As + (16 * wave + cl) * PG_LD + kq;
+    const double* b_r = Bs + cl * PG_LD + kq;
 
     const int nslab = (Km_pad + PG_KT - 1) / PG_KT;
+    const int last_nk = (Km_pad - PG_KT * (nslab - 1)) / 4;   // k-steps of the last slab, 1 .. 4
     fetch(0);
     stash(0);
     __syncthreads();
-    for (int sl = 0; sl < nslab; ++sl) {
+    for (int sl = 0; sl + 1 < nslab; ++sl) {
         const int buf = sl & 1;
-        if (sl + 1 < nslab) fetch((sl + 1) * PG_KT);
-        const double* Ab = As + (buf * PG_TM + 16 * wave + cl) * PG_LD + kq;
-        const double* Bb = Bs + (buf * PG_TM + cl) * PG_LD + kq;
+        fetch((sl + 1) * PG_KT);
+        const double* Ab = a_r + buf * PG_TM * PG_LD;
+        const double* Bb = b_r + buf * PG_TM * PG_LD;
 #pragma unroll
         for (int kk = 0; kk < PG_KT / 4; ++kk) {
             const double a = Ab[4 * kk];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const double b = Bb[16 * t * PG_LD + 4 * kk];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                const double bv = Bb[16 * t * PG_LD + 4 * kk];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
             }
         }
-        if (sl + 1 < nslab) stash(buf ^ 1);
+        stash(buf ^ 1);
         __syncthreads();
     }
+    {
+        const int buf = (nslab - 1) & 1;
+        const double* Ab = a_r + buf * PG_TM * PG_LD;
+        const double* Bb = b_r + buf * PG_TM * PG_LD;
+        for (int kk = 0; kk < last_nk; ++kk) {
+            const double a = Ab[4 * kk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double bv = Bb[16 * t * PG_LD + 4 * kk];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
 
+    // epilogue: R[pe][s] = acc + z sigma_s for this lane's 16 entries -- 8 Box-Muller pairs, the
+    // pair of accumulator registers (2h, 2h+1) = points (pe, pe + 4).  No bounds tests: R has
+    // whole tiles of rows and S_pad columns, sig is zero past S, and a counter past the true
+    // range only costs a wasted variate in the padding.
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t pe0 = p0 + 16 * wave + kq;
+    const int32_t sl0 = s0 + cl;
+    double* r0 = R + pe0 * S_pad + sl0;
+    const uint64_t e0 = (uint64_t)pe0 * (uint64_t)S + (uint64_t)sl0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int32_t s = s0 + 16 * t + cl;
-        const double sg = sig[s];
+        const double sg = sig[sl0 + 16 * t];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {  // registers (2h, 2h+1) = points (pe, pe+4): one Box-Muller pair
-            const int64_t pe = p0 + 16 * wave + kq + 8 * h;
+        for (int h = 0; h < 2; ++h) {
             double z0 = 0.0, z1 = 0.0;
             if (noise_replay == nullptr) {
-                if (s < S && pe < M) pg_noise((uint64_t)pe * (uint64_t)S + (uint64_t)s, k0, k1, z0, z1);
-            } else if (s < S) {
-                if (pe < M) z0 = noise_replay[(int64_t)s * M + pe];
-                if (pe + 4 < M) z1 = noise_replay[(int64_t)s * M + pe + 4];
+                pg_noise(e0 + (uint64_t)(8 * h) * (uint64_t)S + (uint64_t)(16 * t), k0, k1, z0, z1);
+            } else {
+                const int64_t pe = pe0 + 8 * h;
+                const int32_t sd = sl0 + 16 * t;
+                if (sd < S) {
+                    if (pe < M) z0 = noise_replay[(int64_t)sd * M + pe];
+                    if (pe + 4 < M) z1 = noise_replay[(int64_t)sd * M + pe + 4];
+                }
             }
-            if (s < S) {
-                if (pe < M) R[pe * S_pad + s] = fma(z0, sg, acc[t][2 * h]);
-                if (pe + 4 < M) R[(pe + 4) * S_pad + s] = fma(z1, sg, acc[t][2 * h + 1]);
-            }
+            double* rp = r0 + (int64_t)(8 * h) * S_pad + 16 * t;
+            rp[0] = fma(z0, sg, acc[t][2 * h]);
+            rp[(int64_t)4 * S_pad] = fma(z1, sg, acc[t][2 * h + 1]);
         }
     }
 }
@@ -469,22 +555,27 @@ hipError_t launch_transpose_draws(const double* R, int64_t M, int32_t S, int32_t
 
 hipError_t launch_predict(const PredictArgs& a, hipStream_t s) {
     {
-        const int64_t total = (int64_t)a.S_pad * a.Km_pad;
+        const dim3 grid((unsigned)((a.Km_pad + 63) / 64), (unsigned)((a.S_pad + PW_S - 1) / PW_S));
+        hipLaunchKernelGGL(predict_weights_kernel, grid, dim3(256), 0, s, a.theta, a.Vt, a.S, a.k, a.Km,
+                           a.S_pad, a.Km_pad, a.Wt, a.sig);
+    }
+    {
+        const int64_t total = a.M_pad * a.Km_pad;
         int64_t blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(predict_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.theta,
-                           a.Vt, a.S, a.k, a.Km, a.S_pad, a.Km_pad, a.Wt, a.sig);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(predict_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.preds, a.M,
+                           a.Km, a.M_pad, a.Km_pad, a.P);
     }
     {
         // tiles of 64 points x 64 draws, dealt out in super-tiles of PG_ST x PG_ST per XCD
-        const uint32_t ntx = (uint32_t)(a.S_pad / PG_TM), nty = (uint32_t)((a.M + PG_TM - 1) / PG_TM);
+        const uint32_t ntx = (uint32_t)(a.S_pad / PG_TM), nty = (uint32_t)(a.M_pad / PG_TM);
         const uint32_t nsx = (ntx + PG_ST - 1) / PG_ST, nsy = (nty + PG_ST - 1) / PG_ST;
         const uint64_t nsuper8 = ((uint64_t)nsx * nsy + 7) / 8 * 8;
         const uint64_t nblocks = nsuper8 * PG_ST * PG_ST;
         if (nblocks > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(predict_gemm_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, a.preds, a.M,
-                           a.Km, a.Wt, a.sig, a.S, a.S_pad, a.Km_pad, a.seed, a.noise_replay, a.R,
-                           ntx, nty, nsx);
+        hipLaunchKernelGGL(predict_gemm_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, (const double*)a.P,
+                           (const double*)a.Wt, (const double*)a.sig, a.M, a.S, a.S_pad, a.Km_pad, a.seed,
+                           a.noise_replay, a.R, ntx, nty, nsx);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
