@@ -63,7 +63,10 @@ typedef struct {
                                  partition, a GPU shared with another process).  The persistent
                                  kernels need all groups of a launch resident at once; geometry and
                                  the residency check (BMC_EINVAL instead of a spin that times out)
-                                 follow this number                                           */
+                                 follow this number.  The environment variable
+                                 PYBMC_AMD_CU_LIMIT, read by bmc_create, is the default for every
+                                 context of the process (several ranks on one GPU: set each rank's
+                                 share once, e.g. 128 for two)                                 */
 } bmc_tuning;
 
 /* Filled by bmc_gibbs_run*.  Times are HIP-event times on the context's stream. */

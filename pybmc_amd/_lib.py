@@ -170,6 +170,11 @@ class Context:
         # is still there before sampling from it
         self.problem_generation = 0
         self._last_predict = None     # (n_points, n_draws) of the last predict()
+        # a bmc_ctx is driven by one host thread at a time: the functional API
+        # (gibbs_sampler, rndm_m_random_calculator, ...) holds this lock for the whole
+        # set_problem -> set_prior -> run sequence, so that two threads sharing the
+        # per-device context serialise instead of sampling each other's problem
+        self.lock = threading.RLock()
 
     # -- plumbing --------------------------------------------------------------
     def close(self):
@@ -487,11 +492,16 @@ def coverage_plan(n, percentiles):
 
 
 _default_ctx = {}
+_ctx_lock = threading.Lock()
 
 
 def default_context(device=0):
-    """A cached per-device context for the functional API."""
+    """A cached per-device context for the functional API (creation is thread-safe; use
+    ``with ctx.lock:`` around a sequence of calls that belongs together)."""
     ctx = _default_ctx.get(device)
     if ctx is None:
-        ctx = _default_ctx[device] = Context(device)
+        with _ctx_lock:
+            ctx = _default_ctx.get(device)
+            if ctx is None:
+                ctx = _default_ctx[device] = Context(device)
     return ctx

@@ -74,8 +74,9 @@ class BayesianModelCombination:
             from . import _lib
             ctx = _lib.default_context(self.device)
             try:
-                mu, y_c, U_hat, S_hat, Vt_norm = ctx.orthogonalize(
-                    F, train_df[self.truth_column_name].values, k)
+                with ctx.lock:
+                    mu, y_c, U_hat, S_hat, Vt_norm = ctx.orthogonalize(
+                        F, train_df[self.truth_column_name].values, k)
             except np.linalg.LinAlgError as e:
                 raise ValueError(str(e)) from None
             U_hat = np.asfortranarray(U_hat)

@@ -38,6 +38,7 @@ struct bmc_ctx {
     std::string err;
     bmc_tuning tune{};
     int n_cu = 256;
+    int env_cu_limit = 0;   // PYBMC_AMD_CU_LIMIT at bmc_create: the default of bmc_tuning.cu_limit
 
     // problem
     bool have_problem = false, have_prior = false;
@@ -329,7 +330,8 @@ Chip chip_of(const bmc_ctx* c) {
     ch.groups_max = c->n_cu > 0 ? c->n_cu : 256;
     // bmc_tuning.cu_limit: fewer CUs can hold this context's persistent workgroups than the
     // device reports (CU-masked queue, a GPU shared with another process)
-    if (c->tune.cu_limit > 0 && c->tune.cu_limit < ch.groups_max) ch.groups_max = c->tune.cu_limit;
+    const int cu_limit = c->tune.cu_limit > 0 ? c->tune.cu_limit : c->env_cu_limit;
+    if (cu_limit > 0 && cu_limit < ch.groups_max) ch.groups_max = cu_limit;
     if (ch.groups_max > 256) ch.groups_max = 256;   // the gather holds 2 x 256 granules
     ch.xcds = ch.groups_max >= 64 ? ch.groups_max / 32 : 1;
     ch.cu_per_xcd = ch.groups_max / ch.xcds;
@@ -810,6 +812,13 @@ int bmc_create(int device_id, bmc_ctx** out) {
     if (!c) return BMC_ENOMEM;
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
+    // Several processes on one GPU cannot see each other's persistent launches: each is told its
+    // share once, in the environment (e.g. 2 ranks per GPU: PYBMC_AMD_CU_LIMIT=128), and every
+    // context it creates plans for that many CUs unless bmc_tuning.cu_limit says otherwise.
+    if (const char* e = std::getenv("PYBMC_AMD_CU_LIMIT")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v > 0 && v < 100000) c->env_cu_limit = (int)v;
+    }
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;

@@ -19,6 +19,21 @@
 
 namespace bmc {
 
+// fma(a, b, c) with c a compile-time constant of a polynomial.  On the GPU the constant is handed
+// to v_fma_f64 as a scalar-register operand: left to itself hipcc copies every such constant into
+// a vector register pair in front of a v_fmac (two extra vector instructions per coefficient --
+// 32 per Box-Muller pair, and vector instructions are what the predictive GEMM's epilogue is
+// made of).  Same operation, same bits; the CPU build is plain fma.
+BMC_HD double fma_c(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+#else
+    return fma(a, b, c);
+#endif
+}
+
 // natural logarithm of a NORMAL double 0 < x (the generators call it with x in [2^-53, 1])
 BMC_HD double log_normal_arg(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -45,8 +60,8 @@ BMC_HD double log_normal_arg(double x) {
     const double s = f / (2.0 + f);
     const double z = s * s;
     const double w = z * z;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double t1 = w * fma_c(w, fma_c(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_c(w, fma_c(w, fma_c(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double dk = (double)k;
     const double lo = fma(s, hfsq + R, dk * ln2_lo);
@@ -68,10 +83,10 @@ BMC_HD void sincos_2pi(double u, double& sn, double& cs) {
     const double x = r * 1.57079632679489661923;    // |x| <= pi/4
     const double z = x * x;
     const double v = z * x;
-    const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
-    const double ksin = fma(v, fma(z, rs, S1), x);
+    const double rs = fma_c(z, fma_c(z, fma_c(z, fma_c(z, S6, S5), S4), S3), S2);
+    const double ksin = fma(v, fma_c(z, rs, S1), x);
     const double w = z * z;
-    const double rc = fma(w * w, fma(z, fma(z, C6, C5), C4), z * fma(z, fma(z, C3, C2), C1));
+    const double rc = fma(w * w, fma_c(z, fma_c(z, C6, C5), C4), z * fma_c(z, fma_c(z, C3, C2), C1));
     const double hz = 0.5 * z;
     const double w1 = 1.0 - hz;
     const double kcos = w1 + fma(z, rc, (1.0 - w1) - hz);

@@ -41,18 +41,19 @@ def gibbs_sampler(y, X, iterations, prior_info, *, n_chains=1, seeds=None, devic
         raise ValueError('rss must be "data" or "gram"')
     b0, C0, nu0, s20 = prior_info
     ctx = _lib.default_context(device)
-    if not _problem_on_device:   # orthogonalize(method="device") left (y, X) on the GPU
-        ctx.set_problem(y, X, dtype=dtype)
-    ctx.set_prior(b0, C0, nu0, s20)
-    if seeds is None:
-        seeds = _draw_seeds(n_chains)
-    if rss == "gram":
-        ctx.set_tuning(rss_mode=1)
-    try:
-        out, stats = ctx.gibbs_run(n_chains, int(iterations), seeds=seeds)
-    finally:
+    with ctx.lock:   # (the per-device context is shared: one caller's sequence at a time)
+        if not _problem_on_device:   # orthogonalize(method="device") left (y, X) on the GPU
+            ctx.set_problem(y, X, dtype=dtype)
+        ctx.set_prior(b0, C0, nu0, s20)
+        if seeds is None:
+            seeds = _draw_seeds(n_chains)
         if rss == "gram":
-            ctx.set_tuning()
+            ctx.set_tuning(rss_mode=1)
+        try:
+            out, stats = ctx.gibbs_run(n_chains, int(iterations), seeds=seeds)
+        finally:
+            if rss == "gram":
+                ctx.set_tuning()
     res = out[0] if n_chains == 1 else out
     return (res, stats) if return_stats else res
 
@@ -83,10 +84,11 @@ def gibbs_sampler_simplex(y, X, Vt_hat, S_hat, iterations, prior_info, burn=1000
         raise ValueError("Stepsize must be positive.")
     nu0, s20 = prior_info
     ctx = _lib.default_context(device)
-    ctx.set_problem(y, X)
-    if seed is None:
-        seed = int(_draw_seeds(1)[0])
-    samples, accepted = ctx.simplex_run(Vt_hat, S_hat, int(iterations), float(nu0), float(s20),
-                                        int(burn), float(stepsize), seed=seed)
+    with ctx.lock:
+        ctx.set_problem(y, X)
+        if seed is None:
+            seed = int(_draw_seeds(1)[0])
+        samples, accepted = ctx.simplex_run(Vt_hat, S_hat, int(iterations), float(nu0), float(s20),
+                                            int(burn), float(stepsize), seed=seed)
     print(f"Acceptance rate: {accepted / iterations * 100:.2f}%")
     return samples

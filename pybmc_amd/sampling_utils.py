@@ -29,7 +29,8 @@ def rndm_m_random_calculator(filtered_model_predictions, samples, Vt_hat, *, see
     ctx = _lib.default_context(device)
     rng = np.random.Generator(np.random.PCG64(seed))
     theta = rng.choice(samples, N_PREDICTIVE_DRAWS, replace=False)     # :57
-    rndm_m, bands, _ = ctx.predict(preds, theta, Vt_hat, seed=seed)
+    with ctx.lock:
+        rndm_m, bands, _ = ctx.predict(preds, theta, Vt_hat, seed=seed)
     return rndm_m, [bands[0], bands[1], bands[2]]
 
 
@@ -48,8 +49,9 @@ def predictive_coverage(percentiles, filtered_model_predictions, samples, Vt_hat
     rng = np.random.Generator(np.random.PCG64(seed))
     theta = rng.choice(samples, N_PREDICTIVE_DRAWS, replace=False)
     ctx = _lib.default_context(device)
-    _, _, cov = ctx.predict(preds, theta, Vt_hat, seed=seed, q=(), truth=truth,
-                            cov_percentiles=list(percentiles), want_draws=False)
+    with ctx.lock:
+        _, _, cov = ctx.predict(preds, theta, Vt_hat, seed=seed, q=(), truth=truth,
+                                cov_percentiles=list(percentiles), want_draws=False)
     return cov
 
 

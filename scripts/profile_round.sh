@@ -3,7 +3,7 @@
 # passes (a --pmc pass is never combined with a trace domain other than --kernel-trace).
 # usage: bash scripts/profile_round.sh r02      (then: python3 scripts/summarize_profile.py r02)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/prof_$TAG
 rm -rf $OUT   # NOTE: gpurun MERGES into the local gpurun_out/: delete the local copy before the call too
 mkdir -p $OUT

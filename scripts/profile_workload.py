@@ -27,11 +27,12 @@ def dense(n, k, dt, seed=8):
 
 def main():
     ctx = _lib.Context(0)
-    # C2: 8 and 16 chains in one launch (one / two chains per XCD)
+    # C2: 8 and 16 chains in one launch (one / two chains per XCD), 32 and 64 as bundles of 4 / 8
+    # chains per XCD (gibbs_multi_kernel with bundle slots)
     p = synth_problem(10000, 33, 32, seed=0)
     ctx.set_problem(p["y"], p["X"])
     ctx.set_prior(*p["prior"])
-    for c in (8, 16):
+    for c in (8, 16, 32, 64):
         _, st = ctx.gibbs_run(c, 5000, seeds=np.arange(c) + 1)
         print(f"c2 x{c}: {st['loop_ms'] * 1e3 / 5000:.3f} us/iter", flush=True)
     # simplex sampler on the same problem (reference inference_utils.py:59-144)
@@ -62,6 +63,8 @@ def main():
         ctx.predict(preds, theta, Vt, seed=9, truth=preds.mean(1),
                     cov_percentiles=list(range(0, 101, 5)), want_draws=False)
     print("predict c5:", ctx.predict_timing(), flush=True)
+    # and with the draws returned in the reference's layout (device transpose + staged copy)
+    ctx.predict(preds[:8192], theta, Vt, seed=9, want_draws=True)
 
 
 if __name__ == "__main__":

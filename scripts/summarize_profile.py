@@ -18,7 +18,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 F64_MATRIX_PEAK_TF = 78.6   # MI355X datasheet; scripts/micro/mfma_f64_peak.hip sustains 47.4
