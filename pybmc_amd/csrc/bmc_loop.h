@@ -1,6 +1,7 @@
 // Building blocks shared by the persistent loop kernels (Gibbs and simplex samplers):
 // on-chip panel store, XCD placement check, group all-reduce of the partial rss.
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "bmc_dev.h"
@@ -623,6 +624,12 @@ __device__ __forceinline__ void publish_pair(gu64* gp, int g, int lane, unsigned
 struct NoIdleWork {
     __device__ __forceinline__ void operator()() const {}
 };
+// (A/B builds with -DBMC_PRESLEEP: pause only in the passes that serve several chains, whose
+// exchange carries idle work -- the recording -- and eight polling leaders per CU)
+template <bool RELAY, typename F>
+__device__ __forceinline__ constexpr bool RELAY_SLEEP_OK() {
+    return !std::is_same<F, NoIdleWork>::value;
+}
 
 // `idle` runs after this group's total is published and before the polling starts: work placed
 // there is hidden by the store -> polled-load latency the group pays anyway.
@@ -654,6 +661,11 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     if (local) publish_pair<true>(gp1, rank, lane, epoch, s);
     else publish_pair<false>(gp1, rank, lane, epoch, s);
     idle();
+#if defined(BMC_PRESLEEP) && BMC_PRESLEEP > 0
+    // (A/B only: a fixed pause before the first poll -- the hop cannot complete sooner than one
+    // L2 round trip, and every poll that comes back stale loaded the L2 for nothing)
+    if (RELAY_SLEEP_OK<RELAY, F>()) __builtin_amdgcn_s_sleep(BMC_PRESLEEP);
+#endif
     gu64 x;
     ok = granule_gather1(gp1, 2 * members, epoch, lane, x STAMP_ARGS);
     GSTAMP(5);
