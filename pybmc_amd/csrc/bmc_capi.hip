@@ -39,6 +39,7 @@ struct bmc_ctx {
     bmc_tuning tune{};
     int n_cu = 256;
     int env_cu_limit = 0;   // PYBMC_AMD_CU_LIMIT at bmc_create: the default of bmc_tuning.cu_limit
+    uint64_t nonce_state = 0x9E3779B97F4A7C15ull;   // per-launch exchange nonces (launch_nonce)
 
     // problem
     bool have_problem = false, have_prior = false;
@@ -79,6 +80,21 @@ struct bmc_ctx {
 };
 
 namespace {
+
+// Base of a persistent launch's exchange tags (GibbsArgs.epoch0): different for every launch
+// (splitmix64 of a per-context counter), so that words an earlier launch left behind -- in the
+// exchange buffer the launch re-zeroes, or in a cache that still holds a line of it -- can never
+// be taken for this launch's.  Tags are epoch0 + 1 .. epoch0 + n_tags; none may be 0 (the
+// zeroed state), so the base keeps them below 2^32 when the run is short enough to allow it.
+uint32_t launch_nonce(bmc_ctx* c, uint64_t n_tags) {
+    uint64_t z = (c->nonce_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const uint64_t room = 0xffffffffull - (n_tags + 1);   // largest base with no wrap
+    if (n_tags + 2 >= 0xffffffffull) return 0;
+    return (uint32_t)(1 + z % room);
+}
 
 int fail(bmc_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
@@ -735,6 +751,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         }
         a.n_chains = m;
         a.chains_per_pass = cpp;
+        a.epoch0 = launch_nonce(c, (uint64_t)iters);
         if (cpp > cpp_used) cpp_used = cpp;
         if (a.waves > waves_used) waves_used = a.waves;
         a.xi = (const double*)c->xi.p + (size_t)c0 * T * K;
@@ -812,6 +829,7 @@ int bmc_create(int device_id, bmc_ctx** out) {
     if (!c) return BMC_ENOMEM;
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
+    c->nonce_state ^= (uint64_t)(uintptr_t)c * 0xD6E8FEB86659FD93ull;   // contexts differ
     // Several processes on one GPU cannot see each other's persistent launches: each is told its
     // share once, in the environment (e.g. 2 ranks per GPU: PYBMC_AMD_CU_LIMIT=128), and every
     // context it creates plans for that many CUs unless bmc_tuning.cu_limit says otherwise.
@@ -1391,6 +1409,7 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     a.nslot = geo.nslot;
     a.force_agent_scope = c->tune.force_agent_scope;
     a.panels_per_group = geo.ppg;
+    a.epoch0 = launch_nonce(c, (uint64_t)Tt);
     if (a.vt_in_lds && simplex_lds_bytes(a) > LDS_LIMIT) a.vt_in_lds = 0;
     if (simplex_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");
     if (Tt > 0) {

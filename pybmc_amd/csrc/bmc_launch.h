@@ -143,6 +143,8 @@ struct GibbsArgs {
     int32_t nslot;          // grid = nslot x G; 8 = one slot per XCD, else = n_chains
     int32_t force_agent_scope;  // 1: never use the XCD-local exchange
     int32_t chains_per_pass;  // > 1: gibbs_multi_kernel, bundles of that many chains
+    uint32_t epoch0 = 0;      // nonce of this launch: exchange tags are epoch0 + t + 1, placement
+                              // words carry it in their high half (host: never lets a tag be 0)
     int32_t bundle_slots = 0; // gibbs_multi_kernel: 0 = ONE bundle, grid = G (a chain over the whole
                               // chip); > 0 = grid = bundle_slots x G, bundle b = blockIdx % slots
                               // (one bundle per XCD: chains b * cpp .. b * cpp + cpp - 1), n_chains
@@ -198,6 +200,7 @@ struct SimplexArgs {
     long long* counters;    // [2] accepted (sampling phase), uniforms consumed
     int64_t iters, burn;
     int32_t G, waves, mode, reg_ppw, nslot, force_agent_scope, panels_per_group;
+    uint32_t epoch0 = 0;    // as in GibbsArgs
     int32_t* query_occupancy = nullptr;  // as in GibbsArgs
 };
 size_t simplex_lds_bytes(const SimplexArgs& a);

@@ -149,10 +149,14 @@ __device__ __forceinline__ double granule_sum1(gu64 x, int lane) {
 // decide.  G <= 32: 1 = all groups on one XCD.  G > 32 (two-level exchange, teams g mod 8):
 // 1 = every group shares its XCD with the first member of its team, i.e. each team is
 // XCD-local.  Run by wave 0; returns -1 when the spin expired.
-__device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, int lane) {
+// `nonce` (the launch's epoch base, below) tags the words: a word of an earlier launch that a
+// cache still held would not be taken for this launch's.
+__device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, int lane,
+                                                unsigned nonce = 0) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    const gu64 tagv = (gu64)nonce << 32;
     if (lane == 0)
-        __hip_atomic_store(xcc_words + g, (gu64)(xcc + 1), __ATOMIC_RELAXED,
+        __hip_atomic_store(xcc_words + g, tagv | (gu64)(xcc + 1), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     const bool teams = G > 32;
     bool same = true;
@@ -162,14 +166,15 @@ __device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, i
         same = true;
         for (int b = 0; b < G; b += 64) {
             const int idx = b + lane;
-            gu64 w = xcc + 1, lead = xcc + 1;
+            gu64 w = tagv | (xcc + 1), lead = tagv | (xcc + 1);
             if (idx < G) {
                 w = __hip_atomic_load(xcc_words + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (teams)
                     lead = __hip_atomic_load(xcc_words + (idx & 7), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
             }
-            ok = ok && (w != 0) && (lead != 0);
+            // ready = this launch's tag and a non-zero id
+            ok = ok && (w >> 32) == nonce && (unsigned)w != 0 && (lead >> 32) == nonce && (unsigned)lead != 0;
             same = same && (w == lead);
         }
         if (__all(ok)) break;
@@ -188,22 +193,23 @@ __device__ __forceinline__ int detect_placement(gu64* xcc_words, int G, int g, i
 // index and reads all G of them; the answer is c if the placement really is that rotation, -1
 // otherwise (or when the bounded spin expired) -- data every workgroup reads identically, so all
 // take the same decision.  Run by wave 0.
-__device__ __forceinline__ int detect_rotation(gu64* words, int G, int b, int lane) {
+__device__ __forceinline__ int detect_rotation(gu64* words, int G, int b, int lane, unsigned nonce = 0) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+    const gu64 tagv = (gu64)nonce << 32;
     if (lane == 0)
-        __hip_atomic_store(words + b, (gu64)(xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(words + b, tagv | (gu64)(xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long t_start = 0;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true, rot = true;
         const gu64 w0 = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int base = 0; base < G; base += 64) {
             const int idx = base + lane;
-            gu64 w = 1;
+            gu64 w = tagv | 1;
             if (idx < G) w = __hip_atomic_load(words + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && w != 0 && w0 != 0;
-            rot = rot && (idx >= G || ((w - 1) & 7) == ((w0 - 1 + (gu64)idx) & 7));
+            ok = ok && (w >> 32) == nonce && (unsigned)w != 0 && (w0 >> 32) == nonce && (unsigned)w0 != 0;
+            rot = rot && (idx >= G || (((unsigned)w - 1) & 7) == (((unsigned)w0 - 1 + (unsigned)idx) & 7));
         }
-        if (__all(ok)) return __all(rot) ? (int)((w0 - 1) & 7) : -1;
+        if (__all(ok)) return __all(rot) ? (int)(((unsigned)w0 - 1) & 7) : -1;
         if ((spins & 0xff) == 0xff) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (t_start == 0) t_start = now;

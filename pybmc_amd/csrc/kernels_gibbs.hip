@@ -124,7 +124,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
         if (G > 32 && (G & 7) == 0 && a.nslot == 1) {
             __shared__ int rot_c;
             if (wave == 0) {
-                const int c = detect_rotation(a.gran + (size_t)2 * a.gran_stride + 256, G, g, lane);
+                const int c = detect_rotation(a.gran + (size_t)2 * a.gran_stride + 256, G, g, lane, a.epoch0);
                 if (lane == 0) rot_c = c;
             }
             __syncthreads();
@@ -150,7 +150,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
     gu64* gr = a.gran + (size_t)chain * 3 * a.gran_stride;
     if constexpr (!SINGLE) {
         if (wave == 0) {
-            const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane);
+            const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane, a.epoch0);
             if (lane == 0) {
                 if (place < 0) { ctl[1] = 1.0; a.status[chain] = 1; }
                 ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
@@ -203,7 +203,9 @@ void gibbs_loop_kernel(GibbsArgs a) {
     const bool is_leader = ROLE < 0 ? wave == 0 : ROLE == 0;
     const bool is_rec = REC < 0 ? recorder : REC == 1;
     for (int64_t t = 0; t < T_it; ++t) {
-        const unsigned epoch = (unsigned)(t + 1);
+        // (epoch0: the launch's nonce -- a granule an earlier launch left in some cache carries
+        // another base and is never taken for this launch's; 0 is never a live tag)
+        const unsigned epoch = (unsigned)(t + 1) + a.epoch0;
         STAMP(7);
         if (is_leader) {
 #pragma unroll
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     if (!SLOTTED && G > 32 && (G & 7) == 0) {
         __shared__ int rot_c;
         if (wave == 0) {
-            const int c = detect_rotation(gran0 + (size_t)2 * a.gran_stride + 256, G, g, lane);
+            const int c = detect_rotation(gran0 + (size_t)2 * a.gran_stride + 256, G, g, lane, a.epoch0);
             if (lane == 0) rot_c = c;
         }
         __syncthreads();
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
 
     const size_t chain_stride = (size_t)3 * a.gran_stride;
     if (wave == 0) {
-        const int place = detect_placement(gran0 + 2 * a.gran_stride, G, g, lane);
+        const int place = detect_placement(gran0 + 2 * a.gran_stride, G, g, lane, a.epoch0);
         if (lane == 0) {
             if (place < 0) { ctl[1] = 1.0; a.status[chain0] = 1; }
             ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     if (stamping) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
     for (int64_t t = 0; t < T_it; ++t) {
-        const unsigned epoch = (unsigned)(t + 1);
+        const unsigned epoch = (unsigned)(t + 1) + a.epoch0;
         GSTAMP(7);
         double u_rec[KCH];
         const double sp_rec = sp_eff, g_rec = g_eff;   // sigma2 of the previous row
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
 
     gu64* gr = a.gran;
     if (wave == 0) {
-        const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane);
+        const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane, a.epoch0);
         if (lane == 0) {
             if (place < 0) { ctl[1] = 1.0; a.status[0] = 1; }
             ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
 #endif
             const double rss_prop = group_allreduce<false, (MODE == MODE_REG && VEC == 1)>(
                 part, red, gr + (size_t)(nex & 1) * a.gran_stride,
-                                                    G, g, wave, nw, lane, nex + 1, local, got STAMP_ARGS);
+                                                    G, g, wave, nw, lane, nex + 1 + a.epoch0, local, got STAMP_ARGS);
             ++nex;
             if (wave == 0) {
                 if (!got || iu >= a.n_unif) {
