@@ -376,11 +376,12 @@ hipError_t launch_gram(const Panels& P, void* scratch, double* gram_out, hipStre
 // =========================================================================
 // rotate: Xrot = X W
 // =========================================================================
-// One wave produces JT = 8 output columns of one panel: it streams the panel's K
-// input columns once (coalesced, VEC rows per lane) and keeps 8*VEC accumulators.
-constexpr int ROT_JT = 8;
-
-template <typename T, int VEC>
+// One wave produces JT = 8 output columns of one panel: it streams the panel's K input columns
+// once (coalesced, VEC rows per lane) and keeps 8 * VEC accumulators; W[i][j] is wave-uniform
+// (scalar loads).  (Round 3 tried JT = 32 for wide outputs -- a quarter of the L2 re-reads of the
+// panel: C5 0.51 -> 0.68 ms, a quarter of the waves and each waiting on four scalar loads per
+// input column; not kept.  One-off per problem, beside 38 ms of host K x K algebra at K = 256.)
+template <typename T, int VEC, int ROT_JT>
 __global__ __launch_bounds__(256) void rotate_kernel(const T* __restrict__ X,
                                                      const double* __restrict__ W, int32_t K,
                                                      int32_t KO, T* __restrict__ Xrot,
@@ -426,15 +427,16 @@ __global__ __launch_bounds__(256) void rotate_kernel(const T* __restrict__ X,
 template <typename T>
 static hipError_t rotate_dispatch(const Panels& P, const double* W, int32_t ko, void* Xrot,
                                   hipStream_t s) {
-    const uint32_t ncg = (uint32_t)((ko + 4 * ROT_JT - 1) / (4 * ROT_JT));   // column groups per panel
+    constexpr int jt = 8;
+    const uint32_t ncg = (uint32_t)((ko + 4 * jt - 1) / (4 * jt));   // column groups per panel
     const dim3 grid((unsigned)(((P.npanels + 7) / 8) * 8) * ncg);
-#define BMC_ROT(V)                                                                       \
-    hipLaunchKernelGGL((rotate_kernel<T, V>), grid, dim3(256), 0, s, (const T*)P.X, W, P.k, \
+#define BMC_ROT(V, J)                                                                       \
+    hipLaunchKernelGGL((rotate_kernel<T, V, J>), grid, dim3(256), 0, s, (const T*)P.X, W, P.k, \
                        ko, (T*)Xrot, P.npanels, ncg)
     switch (P.vec) {
-        case 1: BMC_ROT(1); break;
-        case 2: BMC_ROT(2); break;
-        case 4: BMC_ROT(4); break;
+        case 1: BMC_ROT(1, jt); break;
+        case 2: BMC_ROT(2, jt); break;
+        case 4: BMC_ROT(4, jt); break;
         default: return hipErrorInvalidValue;
     }
 #undef BMC_ROT

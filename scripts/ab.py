@@ -59,6 +59,10 @@ CASES = {   # name: (problem factory, dtype, chains, iterations)
     "rss_c5": (lambda: dense(50000, 256, np.float64), np.float64, -1, 100),
     "rss_hbm": (lambda: dense(2000000, 64, np.float32), np.float32, -1, 30),
     "rss_c2": (lambda: synth(10000, 32), np.float64, -1, 200),
+    # chains = -2: wall clock of bmc_set_prior (host K x K algebra + residual pass + rotation), ms
+    "prior_c5": (lambda: dense(50000, 256, np.float64), np.float64, -2, 1),
+    "prior_c4": (lambda: dense(200000, 64, np.float32), np.float32, -2, 1),
+    "prior_c2": (lambda: synth(10000, 32), np.float64, -2, 1),
 }
 
 
@@ -98,7 +102,14 @@ def main():
             # rotate the order: the first build timed after a pause gets a slightly higher clock
             order = ctxs[r % len(ctxs):] + ctxs[:r % len(ctxs)]
             for name, c in order:
-                if chains <= 0:
+                if chains == -2:
+                    import time
+                    t0 = time.perf_counter()
+                    c.set_prior(*prior)
+                    times[name].append((time.perf_counter() - t0) * 1e3)
+                    out, st = c.basis()[0], {"groups_per_chain": 0, "waves_per_group": 0,
+                                             "chains_per_pass": 0, "residency": 0}
+                elif chains <= 0:
                     times[name].append((c.gram_bench(reps=iters) if chains == 0
                                         else c.residual_rss_bench(nb=1, reps=iters)) * 1e3)
                     out, st = c.gram(), {"groups_per_chain": 0, "waves_per_group": 0,
