@@ -50,8 +50,12 @@ typedef struct {
     int32_t residency;        /* 0 auto, 1 registers, 2 LDS, 3 stream from HBM */
     int32_t panels_per_wave;  /* register residency: 1, 2 or 4                 */
     int32_t force_agent_scope;/* 1 = never use the XCD-local (L2) exchange     */
-    int32_t chains_per_pass;  /* streamed/LDS panels: chains served by one read of X;
-                                 0 auto (up to 8), 1 off, 2/4/8 cap             */
+    int32_t chains_per_pass;  /* chains served by one read of X (streamed / LDS-pinned panels) or by
+                                 one set of register-resident panels (a chain over the whole chip; or,
+                                 one-XCD shapes such as N = 10000 x 32 with 16 chains or more, a BUNDLE
+                                 per XCD: 16 .. 64 chains per launch, each bit-identical to its solo
+                                 run).  0 auto (up to 8; bundles from 4 chains per XCD on), 1 off,
+                                 2/4/8 cap (2 also asks for bundles of 2)                            */
     int32_t rss_mode;         /* 0 (default): rss = sum (y - X beta)^2 by a pass over the data
                                  every iteration, as inference_utils.py:48-51 does.
                                  1 (opt-in, K <= 64): the same number from sufficient statistics,

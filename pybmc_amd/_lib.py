@@ -206,7 +206,7 @@ class Context:
     def set_tuning(self, groups_per_chain=0, waves_per_group=0, residency=0, panels_per_wave=0,
                    force_agent_scope=0, chains_per_pass=0, rss_mode=0, cu_limit=0):
         """residency: 0 auto, 1 registers, 2 LDS, 3 stream from HBM; chains_per_pass: 0 auto,
-        1 off, 2/4/8 cap; rss_mode: 0 a pass over the data every iteration (the reference's
+        1 off, 2/4/8 cap (chains served per pass over X, or per bundle of an XCD's resident panels); rss_mode: 0 a pass over the data every iteration (the reference's
         computation, default), 1 the same number from sufficient statistics (opt-in, K <= 64);
         cu_limit: plan persistent launches for at most this many CUs (0 = the device's)."""
         t = Tuning(groups_per_chain, waves_per_group, residency, panels_per_wave,

@@ -1,7 +1,6 @@
 // Building blocks shared by the persistent loop kernels (Gibbs and simplex samplers):
 // on-chip panel store, XCD placement check, group all-reduce of the partial rss.
 #pragma once
-#include <type_traits>
 #include <utility>
 
 #include "bmc_dev.h"
@@ -630,12 +629,7 @@ __device__ __forceinline__ void publish_pair(gu64* gp, int g, int lane, unsigned
 struct NoIdleWork {
     __device__ __forceinline__ void operator()() const {}
 };
-// (A/B builds with -DBMC_PRESLEEP: pause only in the passes that serve several chains, whose
-// exchange carries idle work -- the recording -- and eight polling leaders per CU)
-template <bool RELAY, typename F>
-__device__ __forceinline__ constexpr bool RELAY_SLEEP_OK() {
-    return !std::is_same<F, NoIdleWork>::value;
-}
+
 
 // `idle` runs after this group's total is published and before the polling starts: work placed
 // there is hidden by the store -> polled-load latency the group pays anyway.
@@ -667,16 +661,22 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
     if (local) publish_pair<true>(gp1, rank, lane, epoch, s);
     else publish_pair<false>(gp1, rank, lane, epoch, s);
     idle();
-#if defined(BMC_PRESLEEP) && BMC_PRESLEEP > 0
-    // (A/B only: a fixed pause before the first poll -- the hop cannot complete sooner than one
-    // L2 round trip, and every poll that comes back stale loaded the L2 for nothing)
-    if (RELAY_SLEEP_OK<RELAY, F>()) __builtin_amdgcn_s_sleep(BMC_PRESLEEP);
-#endif
+    // (tried in round 3, for the passes whose eight leaders per CU poll at once: a fixed s_sleep
+    // of 128 / 256 / 384 cycles before the first poll -- 64 chains at C2 2.333 / 2.346 / 2.382 against
+    // 2.319 us per iteration without; gpurun_out/r3_ab5.log)
     gu64 x;
     ok = granule_gather1(gp1, 2 * members, epoch, lane, x STAMP_ARGS);
     GSTAMP(5);
+    // (the expired spin leaves at once: as `ok ? sum : 0` the flag travelled through the whole
+    // serial path as set / test / branch pairs)
+#ifndef BMC_NO_EXPECT
+    if (__builtin_expect(!ok, 0)) return 0.0;
+    double tot = granule_sum1(x, lane);
+    if (teams) {
+#else
     double tot = ok ? granule_sum1(x, lane) : 0.0;
     if (teams && ok) {
+#endif
         // second level: 8 team-total pairs, then 8 relay pairs, GRAN_L2_STRIDE words (512 bytes)
         // apart: each pair is written by one XCD and polled by all (bmc_launch.h)
         gu64* gp2 = gp + (size_t)256 * GRAN_PAIR_STRIDE;
@@ -684,14 +684,16 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
         if (rank == 0) publish_pair<false, GRAN_L2_STRIDE>(gp2, team, lane, epoch, tot);
         if (!RELAY || rank == 0) {
             ok = granule_gather1<BMC_POLL_DEPTH2, GRAN_L2_STRIDE>(gp2, 16, epoch, lane, x STAMP_ARGS);
-            tot = ok ? granule_sum1(x, lane) : 0.0;
-            if (RELAY && ok) {
+            if (__builtin_expect(!ok, 0)) return 0.0;
+            tot = granule_sum1(x, lane);
+            if (RELAY) {
                 if (local) publish_pair<true, GRAN_L2_STRIDE>(gp3, 0, lane, epoch, tot);
                 else publish_pair<false, GRAN_L2_STRIDE>(gp3, 0, lane, epoch, tot);
             }
         } else {
             ok = granule_gather1<2, GRAN_L2_STRIDE>(gp3, 2, epoch, lane, x STAMP_ARGS);
-            tot = ok ? granule_sum1(x, lane) : 0.0;   // the relayed double itself (+ zeros)
+            if (__builtin_expect(!ok, 0)) return 0.0;
+            tot = granule_sum1(x, lane);   // the relayed double itself (+ zeros)
         }
     }
     GSTAMP(8);
@@ -708,12 +710,16 @@ __device__ __forceinline__ double exchange_sum(double s, gu64* gp, int G, int g,
 // 1.112 -> 1.085 us, N = 629 0.599 -> 0.570, N = 100 000 x 32 2.25 -> 2.02; but C4 (two rows
 // per lane) 3.26 -> 3.41 and C5 (streamed) 15.8 -> 16.1, which therefore keep the other form:
 // a wave_sum per wave, 8 slots, three DPP steps in wave 0.
-template <bool SINGLE = false, bool LANEWISE = false, int TEAMS = -1, int LOCAL = -1, int ROLE = -1>
+// PREWRITTEN (LANEWISE only): the caller has already left its lane partials in its row of `red`
+// (right behind the residual pass, ahead of its other work in front of the barrier).
+// `idle`: work of the leader placed between publishing the group total and the first poll.
+template <bool SINGLE = false, bool LANEWISE = false, int TEAMS = -1, int LOCAL = -1, int ROLE = -1,
+          bool PREWRITTEN = false, typename F = NoIdleWork>
 __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* gp, int G, int g,
                                                   int wave, int nw, int lane, unsigned epoch,
-                                                  bool local, bool& ok STAMP_PARAMS) {
+                                                  bool local, bool& ok STAMP_PARAMS, F idle = F()) {
     if constexpr (LANEWISE) {
-        red[wave * 64 + lane] = s;
+        if constexpr (!PREWRITTEN) red[wave * 64 + lane] = s;
     } else {
         s = wave_sum(s);
         if (lane == 0) red[wave] = s;
@@ -731,7 +737,7 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
     }
     GSTAMP(4);
     if constexpr (SINGLE) return s;
-    return exchange_sum<false, NoIdleWork, TEAMS, LOCAL>(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS);
+    return exchange_sum<false, F, TEAMS, LOCAL>(s, gp, G, g, lane, epoch, local, ok STAMP_ARGS, idle);
 }
 
 // ---- several chains per pass (streaming / LDS residency) ---------------------------------

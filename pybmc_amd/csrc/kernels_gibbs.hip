@@ -217,6 +217,12 @@ void gibbs_loop_kernel(GibbsArgs a) {
                 if (MODE == MODE_REG || (ch * 64 < K && j < K))
                     u_lds[j] = draw_u(lam_r[ch], c1_r[ch], c2_r[ch], xi_next[ch], sp_eff, g_eff, sq_sp);
             }
+#ifndef BMC_CTL_EARLY
+            // the (sp, g) pair of the sigma2 just drawn, for the recording wave: written here,
+            // behind u, rather than between the sigma2 step and the draw it feeds (both are in
+            // front of barrier B1, after which the recorder reads them)
+            if (lane == 0) { ctl[0] = sp_eff; ctl[3] = g_eff; }
+#endif
         }
         STAMP(0);
         __syncthreads();  // B1: u (and the previous sp, g / abort word) visible to all waves
@@ -253,6 +259,18 @@ void gibbs_loop_kernel(GibbsArgs a) {
 
         // ---- partial rss over this group's panels, then over the chain's groups ---------
         const double part = store.partial_rss(u_lds);
+        constexpr bool LANEWISE = (MODE == MODE_REG && VEC == 1);
+#ifndef BMC_TAIL
+#define BMC_TAIL 1
+#endif
+        // (round 3) BMC_TAIL 1: the lane partials go to LDS at once, ahead of the abort test and
+        // the leader's prefetch (stamps had 216 cycles between the end of the pass and the LDS
+        // write -- on the leader's way to the group barrier, i.e. on every wave's).  2: the
+        // prefetch moved behind the publication of the group total as well -- slower (C2 0.945 ->
+        // 0.984 us): vmcnt counts in order, so the polls then wait for the prefetch's L2 misses.
+        constexpr bool EARLY = (BMC_TAIL >= 1) && LANEWISE && !SINGLE;
+        constexpr bool IDLE_PREFETCH = (BMC_TAIL >= 2) && EARLY;
+        if constexpr (EARLY) red[wave * 64 + lane] = part;
         {   // (the empty asm ties the test to `part`, or hipcc moves it back up)
             double abort_late = abort_w;
             asm volatile("" : "+v"(abort_late) : "v"(part));
@@ -262,11 +280,12 @@ void gibbs_loop_kernel(GibbsArgs a) {
         // behind the residual pass: issued in front of it, hipcc made wave 0's first FMA wait
         // for these loads (vmcnt is in-order and the panel registers were loaded "before" them
         // as far as the loop header can tell); the exchange hides them here
-        if constexpr (!SINGLE) prefetch();
+        if constexpr (!SINGLE && !IDLE_PREFETCH) prefetch();
         bool got;
-        const double rss = group_allreduce<SINGLE, (MODE == MODE_REG && VEC == 1), (SMALLG ? 0 : -1), LOCALK, ROLE>(
-            part, red, gr + (size_t)(t & 1) * a.gran_stride,
-                                                   G, g, wave, nw, lane, epoch, local, got STAMP_ARGS);
+        auto idle_prefetch = [&]() { if constexpr (IDLE_PREFETCH) prefetch(); };
+        const double rss = group_allreduce<SINGLE, LANEWISE, (SMALLG ? 0 : -1), LOCALK, ROLE, EARLY>(
+            part, red, gr + (size_t)(t & 1) * a.gran_stride, G, g, wave, nw, lane, epoch, local,
+            got STAMP_ARGS, idle_prefetch);
         STAMP(8);
         if (is_rec) {
             // row t = [u_t, .]; sigma of the PREVIOUS row (its sp, g were final at B1)
@@ -278,7 +297,7 @@ void gibbs_loop_kernel(GibbsArgs a) {
             if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
         }
         if (is_leader) {
-            if (!got) {
+            if (__builtin_expect(!got, 0)) {
                 if (lane == 0) { ctl[1] = 1.0; a.status[chain] = 1; }
             } else {
                 // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
@@ -287,11 +306,17 @@ void gibbs_loop_kernel(GibbsArgs a) {
                 sp_eff = floor_hit ? 1e-6 : scale_post;
                 g_eff = floor_hit ? 1.0 : gam_t;
                 sq_sp = BMC_SQRT_OF(sp_eff);
+#ifdef BMC_CTL_EARLY
                 if (lane == 0) { ctl[0] = sp_eff; ctl[3] = g_eff; }
+#endif
             }
             STAMP(6);
         }
     }
+#ifndef BMC_CTL_EARLY
+    // (the last sigma2, for the row recorded behind the loop)
+    if (is_leader && lane == 0 && ctl[1] == 0.0) { ctl[0] = sp_eff; ctl[3] = g_eff; }
+#endif
     };   // run_loop
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -522,7 +547,7 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
                                              chain_stride, G, g, wave, nw, lane, epoch, local,
                                              got STAMP_ARGS, record);
         if (leader) {
-            if (!got) {
+            if (__builtin_expect(!got, 0)) {
                 if (lane == 0) { ctl[1] = 1.0; a.status[chain] = 1; }
             } else {
                 const double scale_post = (a.nu0_s20 + rss) * 0.5;
