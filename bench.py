@@ -482,7 +482,10 @@ def residual_roofline(rc4):
             "traffic": traffic, "traffic_source": tr.get("source"),
             "traffic_over_algorithmic": (traffic / rc4["bytes_per_pass"]) if traffic else None,
             "profiled_kernel": tr.get("kernel"), "profiled_avg_ms": prof_ms,
-            "traffic_stale": (abs(prof_ms - ms) / ms > 0.05) if prof_ms else None,
+            # (a 10 us kernel moves by +- 10 % from box to box and run to run: the counters are
+            # called stale only when the profiled time is more than 25 % off)
+            "traffic_stale": (abs(prof_ms - ms) / ms > 0.25) if prof_ms else None,
+            "ms_per_launch_runs": rc4.get("ms_per_pass_runs"),
             "served_from": rc4["served_from"], "note": rc4["note"]}
 
 
@@ -635,11 +638,15 @@ def extras(ctx, torch, dev, local_rank, N, K, T):
         y4 = rng.standard_normal(200000, dtype=np.float32)
         c4 = _lib.Context(local_rank)
         c4.set_problem(y4, X4, dtype=np.float32)
-        ms = c4.residual_rss_bench(nb=1, reps=50)
+        # (best of three runs of 50 back-to-back launches: a 10 us kernel right behind a 52 MB
+        # upload sees the clock still ramping; the spread is reported)
+        runs4 = [c4.residual_rss_bench(nb=1, reps=50) for _ in range(3)]
+        ms = min(runs4)
         b4 = (200000 * 64 + 200000) * 4
         extra["residual_rss_c4"] = {"ms_per_pass": ms, "achieved_GBs": b4 / (ms * 1e-3) / 1e9,
                                     "frac_of_8TBs": b4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "bytes_per_pass": b4, "served_from": "infinity cache",
+                                    "ms_per_pass_runs": runs4,
                                     "note": "52 MB working set: served by the 256 MiB "
                                             "Infinity Cache after the first pass"}
         del X4, y4
