@@ -531,6 +531,28 @@ def test_bundles_of_chains_per_xcd(nch, cpp, launches, ask):
     assert np.array_equal(off, out[:min(nch, 20)])
 
 
+def test_bundles_replay_the_reference_chain():
+    """The reference's own C2 chain (golden fixture, its innovations expressed in the library's
+    basis) replayed in all 32 slots of a launch of bundles (4 chains per XCD): every slot must
+    reproduce it (T2 bar) and all slots must agree bit for bit."""
+    ctx = gpu_ctx()
+    g, y, X, prior = golden_case("gibbs_c2_10000x32")
+    ctx.set_problem(y, X)
+    ctx.set_prior(*prior)
+    T = int(g["T"])
+    st, xi, ref = replay_inputs(ctx, g, y, X, prior, T)
+    nch = 32
+    out, stats = ctx.gibbs_run(nch, T, xi=np.repeat(xi[None], nch, 0), g=np.repeat(g["G"][None, :T], nch, 0))
+    assert stats["chains_per_pass"] == 4 and stats["launches"] == 1 and stats["residency"] == 1
+    for c in range(nch):
+        assert np.array_equal(out[c], out[0])
+    assert np.abs(out[0] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    Vt_hat = (g["Vt"] / g["S_hat"][:, None]) if "Vt" in g else None
+    a, b = posterior_summary(out[0], Vt_hat), posterior_summary(ref, Vt_hat)
+    for key in b:
+        assert rel(a[key], b[key]) < REL_BAR, key
+
+
 @pytest.mark.parametrize("n,k,dt,nch", [(100000, 32, np.float64, 8), (120000, 7, np.float64, 5),
                                         (200000, 64, np.float32, 8), (150000, 20, np.float32, 4)])
 def test_several_chains_per_pass_register_residency(n, k, dt, nch):
