@@ -134,16 +134,17 @@ def run_on_devices(y, X, iterations, prior_info, n_chains, seeds, devices, dtype
     blocks = [chain_block(n_chains, len(devs), i) for i in range(len(devs))]
     results, errors = [None] * len(devs), [None] * len(devs)
     b0, C0, nu0, s20 = prior_info
-    ctxs = [_lib.default_context(d) for d in devs]   # (created here: the cache is not thread-safe)
+    ctxs = [_lib.default_context(d) for d in devs]
 
     def work(i):
         try:
             if not blocks[i]:
                 return
             ctx = ctxs[i]
-            ctx.set_problem(y, X, dtype=dtype)
-            ctx.set_prior(b0, C0, nu0, s20)
-            results[i] = ctx.gibbs_run(len(blocks[i]), int(iterations), seeds=seeds[blocks[i]])
+            with ctx.lock:   # (the per-device context is shared with the functional API)
+                ctx.set_problem(y, X, dtype=dtype)
+                ctx.set_prior(b0, C0, nu0, s20)
+                results[i] = ctx.gibbs_run(len(blocks[i]), int(iterations), seeds=seeds[blocks[i]])
         except BaseException as e:     # re-raised on the calling thread
             errors[i] = e
 

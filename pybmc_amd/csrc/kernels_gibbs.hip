@@ -38,6 +38,10 @@
 // every group leaves the loop.
 #include "bmc_loop.h"
 
+#ifndef BMC_LEADER_PRIO
+#define BMC_LEADER_PRIO 3      // s_setprio of the leader wave of a group (0: leave it alone)
+#endif
+
 namespace bmc {
 
 // u_j | sigma2 with sigma2 = sp / g (the beta | sigma2 draw of inference_utils.py:41-45 in the
@@ -202,9 +206,6 @@ void gibbs_loop_kernel(GibbsArgs a) {
     constexpr int ROLE = decltype(role_c)::value, REC = decltype(rec_c)::value;
     const bool is_leader = ROLE < 0 ? wave == 0 : ROLE == 0;
     const bool is_rec = REC < 0 ? recorder : REC == 1;
-#ifndef BMC_LEADER_PRIO
-#define BMC_LEADER_PRIO 3
-#endif
     // The leader wave carries the serial chain of the iteration; the wave that shares its SIMD
     // (five waves on four SIMDs at C2; in group 0 that wave also records the draws) otherwise
     // takes issue slots from it whenever both are ready.  Same-box A/B, s_setprio 3 for the
@@ -730,6 +731,9 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
         if (a.n_unif > 0) unif_next = a.unif[0];
     }
 
+#if BMC_LEADER_PRIO > 0
+    if (wave == 0) __builtin_amdgcn_s_setprio(BMC_LEADER_PRIO);   // (the leader, as in gibbs_loop_kernel)
+#endif
     for (int64_t t = 0; t < T_tot; ++t) {
         if (wave == 0) {
             // proposal b_cur + diag(S_hat stepsize) xi  (:98,:121: mvn with a diagonal cov)

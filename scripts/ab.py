@@ -63,6 +63,8 @@ CASES = {   # name: (problem factory, dtype, chains, iterations)
     "prior_c5": (lambda: dense(50000, 256, np.float64), np.float64, -2, 1),
     "prior_c4": (lambda: dense(200000, 64, np.float32), np.float32, -2, 1),
     "prior_c2": (lambda: synth(10000, 32), np.float64, -2, 1),
+    # chains = -3: the simplex-constrained sampler (reference inference_utils.py:59-144), us per step
+    "simplex_c2": (lambda: synth(10000, 32), np.float64, -3, 20000),
 }
 
 
@@ -102,7 +104,13 @@ def main():
             # rotate the order: the first build timed after a pause gets a slightly higher clock
             order = ctxs[r % len(ctxs):] + ctxs[:r % len(ctxs)]
             for name, c in order:
-                if chains == -2:
+                if chains == -3:
+                    p_ = synth_problem(10000, 33, 32, seed=0)
+                    Vt_hat = p_["Vt"] / p_["S_hat"][:, None]
+                    out, acc, used, st = c.simplex_run(Vt_hat, p_["S_hat"], iters, 1.0, 0.02, 1000, 0.001,
+                                                       seed=3, return_stats=True)
+                    times[name].append(st["loop_ms"] * 1e3 / (iters + 1000))
+                elif chains == -2:
                     import time
                     t0 = time.perf_counter()
                     c.set_prior(*prior)

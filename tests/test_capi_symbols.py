@@ -78,3 +78,33 @@ def test_graft_entry_build_passes():
         sys.path.insert(0, root)
     entry = importlib.import_module("__graft_entry__")
     entry.build()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pybmc_amd.h is the drop-in boundary: it must compile as C99 on its own (no C++,
+    no HIP or torch types), and a C caller must link against the library by name alone."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "pybmc_amd.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / "caller.c"
+    src.write_text(
+        '#include "pybmc_amd.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "    bmc_ctx* ctx = 0;\n"
+        "    printf(\"abi %d\\n\", bmc_abi_version());\n"
+        "    /* no GPU in the build container: create must fail with a status, not crash */\n"
+        "    int rc = bmc_create(0, &ctx);\n"
+        "    printf(\"create %d\\n\", rc);\n"
+        "    if (rc == BMC_OK) bmc_destroy(ctx);\n"
+        "    return 0;\n}\n")
+    exe = tmp_path / "caller"
+    libdir = os.path.join(ROOT, "pybmc_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lpybmc_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "abi 4" in r.stdout and "create" in r.stdout
