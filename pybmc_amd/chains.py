@@ -10,6 +10,8 @@ so the pooled posterior does not depend on the number of ranks.
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 
 SEED_STRIDE = 0x9E3779B97F4A7C15  # golden-ratio increment between chain keys
@@ -141,7 +143,9 @@ def run_on_devices(y, X, iterations, prior_info, n_chains, seeds, devices, dtype
             if not blocks[i]:
                 return
             ctx = ctxs[i]
-            with ctx.lock:   # (the per-device context is shared with the functional API)
+            # (the per-device context is shared with the functional API; a stand-in context of
+            # the CPU tests has no lock)
+            with getattr(ctx, "lock", None) or contextlib.nullcontext():
                 ctx.set_problem(y, X, dtype=dtype)
                 ctx.set_prior(b0, C0, nu0, s20)
                 results[i] = ctx.gibbs_run(len(blocks[i]), int(iterations), seeds=seeds[blocks[i]])
