@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void predict_weights_kernel(
 // D: col = l&15, row = (l>>4) + 4*reg.
 //
 // What bounds it (round 3, scripts/micro/mfma_valu_overlap.hip): on gfx950 a saturated
-// v_mfma_f64_16x16x4_f64 stream (64 cycles per instruction and SIMD = the 78.6 TF of the
-// datasheet, reached with two MFMA waves per SIMD) does NOT overlap with vector-ALU work of
+// v_mfma_f64_16x16x4_f64 stream (64 cycles per instruction and SIMD: 72-77 TF of the datasheet's
+// 78.6 in a 1 ms burst, reached with two MFMA waves per SIMD) does NOT overlap with vector-ALU work of
 // other waves on the same SIMD -- f64, f32 and integer alike: 2 MFMA + 2 VALU waves per SIMD take
 // the SUM of their times, to the percent.  The kernel's time is therefore
 // (MFMA instructions x 64 + VALU instructions x ~4) cycles per SIMD, and the lever is the VALU

@@ -66,8 +66,41 @@ static float run(double* out, int blocks, int nm, int nv) {
     return ms;
 }
 
+// all eight waves of a workgroup on MFMAs (mask 0) or only the even ones (mask 1, as above)
+__global__ __launch_bounds__(512) void mfma_only(double* out, int n, int mask) {
+    const int wave = threadIdx.x >> 6;
+    double r = 0.0;
+    if ((wave & mask) == 0) {
+        d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+        for (int i = 0; i < n; ++i) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+        }
+        r = a0[0] + a1[1] + a2[2] + a3[3];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = r;
+}
+
 int main() {
     double* out; (void)hipMalloc(&out, 8 * 512 * 4096);
+    {
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int mask : {1, 0})
+            for (int blocks : {256, 512}) {
+                const int n = 4000;
+                hipLaunchKernelGGL(mfma_only, dim3(blocks), dim3(512), 0, 0, out, 400, mask);
+                (void)hipEventRecord(e0);
+                hipLaunchKernelGGL(mfma_only, dim3(blocks), dim3(512), 0, 0, out, n, mask);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                const int mw = mask ? 4 : 8;
+                printf("%d workgroups of 8 waves, %d of them on MFMAs: %.3f ms = %.1f TFLOP/s f64\n", blocks, mw, ms,
+                       (double)blocks * mw * n * 4 * 2048.0 / ms / 1e9);
+            }
+    }
     const char* names[3] = {"f64 FMA", "u32 mul/mulhi", "f32 FMA"};
     for (int wg_per_cu : {1, 2}) {
         const int blocks = 256 * wg_per_cu;   // 8 waves per workgroup: 4 MFMA + 4 VALU waves
