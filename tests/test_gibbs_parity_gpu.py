@@ -531,6 +531,29 @@ def test_bundles_of_chains_per_xcd(nch, cpp, launches, ask):
     assert np.array_equal(off, out[:min(nch, 20)])
 
 
+@pytest.mark.parametrize("n,k,dt", [(10000, 8, np.float64), (10000, 64, np.float64), (9000, 16, np.float32),
+                                    (12000, 64, np.float32), (5000, 20, np.float64)])
+def test_bundles_other_widths_and_storage(n, k, dt):
+    """The bundle kernel's other instantiations (8 / 16 / 32 / 64 columns, f32 storage; 64 columns
+    load the chains' u in two chunks; N = 5000 leaves some waves without a panel of their own and
+    several sharing the last one): 64 chains in one launch, probes bit-identical to solo runs."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(n + k)
+    X = (rng.standard_normal((n, k)) / np.sqrt(n)).astype(dt)
+    y = (X.astype(np.float64) @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)).astype(dt)
+    ctx.set_problem(y, np.asfortranarray(X), dtype=dt)
+    ctx.set_prior(np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+    T, nch = 200, 64
+    seeds = np.arange(nch) + 77
+    out, st = ctx.gibbs_run(nch, T, seeds=seeds)
+    assert st["residency"] == 1 and st["chains_per_pass"] == 8 and st["launches"] == 1, st
+    assert np.isfinite(out).all()
+    for c in (0, 7, 8, 33, 63):
+        solo, st1 = ctx.gibbs_run(1, T, seeds=seeds[c:c + 1])
+        assert st1["groups_per_chain"] == st["groups_per_chain"]
+        assert np.array_equal(out[c], solo[0]), (c, st, st1)
+
+
 def test_bundles_replay_the_reference_chain():
     """The reference's own C2 chain (golden fixture, its innovations expressed in the library's
     basis) replayed in all 32 slots of a launch of bundles (4 chains per XCD): every slot must
