@@ -726,6 +726,9 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
             if (c->tune.chains_per_pass > 1 && c->tune.chains_per_pass < cap) cap = c->tune.chains_per_pass;
             cpp = 2;
             while (cpp * 2 <= cap && cpp * 2 * xcds <= left) cpp *= 2;
+            // 40 .. 63 chains: bundles of 8 on 5 .. 7 XCDs in one launch (2.3 us per iteration at C2)
+            // rather than bundles of 4 on all 8 (1.8 us for 32 of them) plus a second launch
+            if (cap >= 8 && cpp == 4 && left >= 5 * 8) cpp = 8;
             const int bundles = left / cpp < xcds ? left / cpp : xcds;
             m = bundles * cpp;
             a.bundle_slots = xcds;
