@@ -665,7 +665,9 @@ hipError_t launch_gibbs_gram(const GramArgs& a, hipStream_t s) {
 // :124): every group evaluates the simplex test on identical bits, so all skip together;
 // the exchange epoch counts exchanges, not iterations.
 // ======================================================================================
-template <typename T, int VEC, int MODE, int KMAX, int PPW>
+// SINGLE: the chain lives in ONE workgroup (G == 1, register residency: the reference's own
+// sizes): nothing to exchange -- as a run-time test it cost the multi-group shapes 2 %.
+template <typename T, int VEC, int MODE, int KMAX, int PPW, bool SINGLE = false>
 __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
     constexpr int RP = 64 * VEC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -697,16 +699,18 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
     store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y));
 
     gu64* gr = a.gran;
-    if (wave == 0) {
-        const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane, a.epoch0);
-        if (lane == 0) {
-            if (place < 0) { ctl[1] = 1.0; a.status[0] = 1; }
-            ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
+    if constexpr (!SINGLE) {
+        if (wave == 0) {
+            const int place = detect_placement(gr + 2 * a.gran_stride, G, g, lane, a.epoch0);
+            if (lane == 0) {
+                if (place < 0) { ctl[1] = 1.0; a.status[0] = 1; }
+                ctl[2] = (place == 1 && !a.force_agent_scope) ? 1.0 : 0.0;
+            }
         }
     }
     __syncthreads();
     const bool local = ctl[2] != 0.0;
-    if (g == 0 && tid == 0) a.placement[0] = local ? 1 : 0;
+    if (g == 0 && tid == 0) a.placement[0] = (local || SINGLE) ? 1 : 0;
 
     // lane-chunks of 64 columns: one, known at compile time, in register mode (K <= 64)
     constexpr int KCH = (MODE == MODE_REG) ? 1 : MAX_KCH;
@@ -786,9 +790,11 @@ __global__ __launch_bounds__(512) void simplex_loop_kernel(SimplexArgs a) {
             bool stamping = false;
             unsigned long long acc_[12] = {}, last_ = 0;
 #endif
-            const double rss_prop = group_allreduce<false, (MODE == MODE_REG && VEC == 1)>(
-                part, red, gr + (size_t)(nex & 1) * a.gran_stride,
-                                                    G, g, wave, nw, lane, nex + 1 + a.epoch0, local, got STAMP_ARGS);
+            // (a chain in ONE workgroup has nothing to exchange: without SINGLE it published its
+            // total and polled it back through L2 -- N = 629: 1.55 -> 1.32 us per step)
+            const double rss_prop = group_allreduce<SINGLE, (MODE == MODE_REG && VEC == 1)>(
+                part, red, gr + (size_t)(nex & 1) * a.gran_stride, G, g, wave, nw, lane,
+                nex + 1 + a.epoch0, local, got STAMP_ARGS);
             ++nex;
             if (wave == 0) {
                 if (!got || iu >= a.n_unif) {
@@ -901,6 +907,12 @@ static hipError_t launch_one(GibbsTag, const GibbsArgs& a, hipStream_t s) {
 }
 template <typename T, int VEC, int MODE, int KMAX, int PPW>
 static hipError_t launch_one(SimplexTag, const SimplexArgs& a, hipStream_t s) {
+    if constexpr (MODE == MODE_REG) {
+        if (a.G == 1)
+            return launch_or_query((const void*)simplex_loop_kernel<T, VEC, MODE, KMAX, PPW, true>,
+                                   dim3(a.nslot * a.G), dim3(64 * a.waves), simplex_lds_bytes(a), s, a,
+                                   a.query_occupancy);
+    }
     return launch_or_query((const void*)simplex_loop_kernel<T, VEC, MODE, KMAX, PPW>,
                            dim3(a.nslot * a.G), dim3(64 * a.waves), simplex_lds_bytes(a), s, a,
                            a.query_occupancy);

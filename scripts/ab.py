@@ -65,6 +65,7 @@ CASES = {   # name: (problem factory, dtype, chains, iterations)
     "prior_c2": (lambda: synth(10000, 32), np.float64, -2, 1),
     # chains = -3: the simplex-constrained sampler (reference inference_utils.py:59-144), us per step
     "simplex_c2": (lambda: synth(10000, 32), np.float64, -3, 20000),
+    "simplex_small": (lambda: synth(629, 3), np.float64, -3, 50000),
 }
 
 
@@ -105,7 +106,7 @@ def main():
             order = ctxs[r % len(ctxs):] + ctxs[:r % len(ctxs)]
             for name, c in order:
                 if chains == -3:
-                    p_ = synth_problem(10000, 33, 32, seed=0)
+                    p_ = synth_problem(y.shape[0], X.shape[1] + 1, X.shape[1], seed=0)
                     Vt_hat = p_["Vt"] / p_["S_hat"][:, None]
                     out, acc, used, st = c.simplex_run(Vt_hat, p_["S_hat"], iters, 1.0, 0.02, 1000, 0.001,
                                                        seed=3, return_stats=True)
