@@ -720,7 +720,7 @@ __device__ __forceinline__ double group_allreduce(double s, double* red, gu64* g
                                                   bool local, bool& ok STAMP_PARAMS, F idle = F()) {
     if constexpr (LANEWISE) {
         if constexpr (!PREWRITTEN) red[wave * 64 + lane] = s;
-    } else {
+    } else if constexpr (!PREWRITTEN) {
         s = wave_sum(s);
         if (lane == 0) red[wave] = s;
     }

@@ -277,9 +277,19 @@ void gibbs_loop_kernel(GibbsArgs a) {
         // write -- on the leader's way to the group barrier, i.e. on every wave's).  2: the
         // prefetch moved behind the publication of the group total as well -- slower (C2 0.945 ->
         // 0.984 us): vmcnt counts in order, so the polls then wait for the prefetch's L2 misses.
-        constexpr bool EARLY = (BMC_TAIL >= 1) && LANEWISE && !SINGLE;
-        constexpr bool IDLE_PREFETCH = (BMC_TAIL >= 2) && EARLY;
-        if constexpr (EARLY) red[wave * 64 + lane] = part;
+        // (BMC_TAIL 3: the same for the wave-sum form of the group sum -- two rows per lane,
+        // LDS-pinned and streamed panels: the wave's total goes to its slot before the abort test.
+        // Same-box A/B: C4 3.067 -> 3.057, C5 15.76 -> 15.80, 410 MB 62.0 -> 64.2 us: not the default)
+        constexpr bool EARLY = ((BMC_TAIL >= 1) && LANEWISE && !SINGLE) || ((BMC_TAIL == 3) && !SINGLE);
+        constexpr bool IDLE_PREFETCH = (BMC_TAIL == 2) && EARLY;
+        if constexpr (EARLY) {
+            if constexpr (LANEWISE) {
+                red[wave * 64 + lane] = part;
+            } else {
+                const double ws = wave_sum(part);
+                if (lane == 0) red[wave] = ws;
+            }
+        }
         {   // (the empty asm ties the test to `part`, or hipcc moves it back up)
             double abort_late = abort_w;
             asm volatile("" : "+v"(abort_late) : "v"(part));
