@@ -245,8 +245,11 @@ __global__ __launch_bounds__(256) void predict_gemm_kernel(
                 }
             }
             double* rp = r0 + (int64_t)(8 * h) * S_pad + 16 * t;
-            rp[0] = fma(z0, sg, acc[t][2 * h]);
-            rp[(int64_t)4 * S_pad] = fma(z1, sg, acc[t][2 * h + 1]);
+            // (non-temporal: the 4 GB of draws are written once and read back by another kernel
+            // long after they have left every cache; kept out of L2 they do not displace the
+            // operand slabs of the super-tile -- same-box A/B 7.16 -> 7.05 ms)
+            __builtin_nontemporal_store(fma(z0, sg, acc[t][2 * h]), rp);
+            __builtin_nontemporal_store(fma(z1, sg, acc[t][2 * h + 1]), rp + (int64_t)4 * S_pad);
         }
     }
 }
