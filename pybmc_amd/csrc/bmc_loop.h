@@ -413,6 +413,9 @@ struct PanelStore {
                             acc[i][v][0] = (double)yr[i][v];
                             acc[i][v][1] = acc[i][v][2] = acc[i][v][3] = 0.0;
                         }
+                    // (tried in round 3: u_j of the first 4 / 8 columns of every block of 16 from an LDS
+                    // broadcast read + plain v_fma_f64 instead of the DPP form, the LDS pipe being idle
+                    // in this pass -- 64 chains at C2 2.34 -> 2.53 / 2.77 us per iteration: rejected)
                     static_for<KMAX>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
 #pragma unroll
