@@ -285,6 +285,26 @@ __device__ __forceinline__ void fmac_rowbcast_neg(double& acc, double u_rows, do
             : "+v"(acc) : "v"(u_rows), "v"(x), "n"(N));
 }
 
+// A whole block of 16 columns in ONE statement (one row per lane: four accumulators, column j into
+// accumulator j mod 4, as everywhere): the two wait states in front of the first DPP read and the
+// sixteen reads are issued together, so nothing -- no register copy, reload or re-materialised
+// value of the allocator's, no compiler-inserted s_nop -- can come between them (round-2 advisor
+// finding: statement by statement only the FIRST of a block carried its own s_nop).  Same
+// instructions, operands and order as sixteen fmac_rowbcast_neg statements.
+__device__ __forceinline__ void fmac16_rowbcast_neg(double (&a)[4], double u_rows, const double (&x)[16]) {
+#define BMC_F(A, X, N) "v_fmac_f64_dpp %" #A ", %4, -%" #X " row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t"
+        BMC_F(0, 5, 0) BMC_F(1, 6, 1) BMC_F(2, 7, 2) BMC_F(3, 8, 3)
+        BMC_F(0, 9, 4) BMC_F(1, 10, 5) BMC_F(2, 11, 6) BMC_F(3, 12, 7)
+        BMC_F(0, 13, 8) BMC_F(1, 14, 9) BMC_F(2, 15, 10) BMC_F(3, 16, 11)
+        BMC_F(0, 17, 12) BMC_F(1, 18, 13) BMC_F(2, 19, 14) BMC_F(3, 20, 15)
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+        : "v"(u_rows), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]),
+          "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]),
+          "v"(x[15]));
+#undef BMC_F
+}
+
 template <typename F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -416,6 +436,17 @@ struct PanelStore {
                     // (tried in round 3: u_j of the first 4 / 8 columns of every block of 16 from an LDS
                     // broadcast read + plain v_fma_f64 instead of the DPP form, the LDS pipe being idle
                     // in this pass -- 64 chains at C2 2.34 -> 2.53 / 2.77 us per iteration: rejected)
+#ifndef BMC_NO_BLOCK_ASM
+                    if constexpr (PPW * VEC == 1 && KMAX % 16 == 0 && sizeof(T) == 8) {
+                        static_for<NU>([&](auto rc) {      // (one statement per block of 16 columns)
+                            constexpr int r = decltype(rc)::value;
+                            double xb[16];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) xb[q] = (double)xr[0][16 * r + q][0];
+                            fmac16_rowbcast_neg(acc[0][0], urow[c][r], xb);
+                        });
+                    } else
+#endif
                     static_for<KMAX>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
 #pragma unroll
@@ -555,6 +586,17 @@ struct PanelStore {
                 double urow[NU];
 #pragma unroll
                 for (int r = 0; r < NU; ++r) urow[r] = u_lds[r * 16 + (lane & 15)];
+#ifndef BMC_NO_BLOCK_ASM
+                if constexpr (JD == 0 && PPW * VEC == 1 && KMAX % 16 == 0 && sizeof(T) == 8) {
+                    static_for<NU>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        double xb[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) xb[q] = (double)xr[0][16 * r + q][0];
+                        fmac16_rowbcast_neg(acc[0][0], urow[r], xb);
+                    });
+                } else
+#endif
                 static_for<KMAX - JD>([&](auto jc) {
                     constexpr int j = decltype(jc)::value + JD;
 #pragma unroll
