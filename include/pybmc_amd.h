@@ -48,7 +48,9 @@ typedef struct {
     int32_t groups_per_chain; /* workgroups that share one chain's rows        */
     int32_t waves_per_group;  /* 1..8 (workgroup = 64 * waves threads)         */
     int32_t residency;        /* 0 auto, 1 registers, 2 LDS, 3 stream from HBM */
-    int32_t panels_per_wave;  /* register residency: 1, 2 or 4                 */
+    int32_t panels_per_wave;  /* register residency: 1, 2 or 4 (1, asked for explicitly, also keeps
+                                 bundles of 8 chains in the one-panel-per-wave layout instead of
+                                 the balanced two-panel one; results are bit-identical) */
     int32_t force_agent_scope;/* 1 = never use the XCD-local (L2) exchange     */
     int32_t chains_per_pass;  /* chains served by one read of X (streamed / LDS-pinned panels) or by
                                  one set of register-resident panels (a chain over the whole chip; or,

@@ -713,6 +713,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         const int left = n_chains - c0;
         int cpp = 1, m, resident;
         a.bundle_slots = 0;
+        a.bundle_bal = 0;
         a.pack = 0;
         a.nslot = geo.nslot;
         // bundles pay from 4 chains per XCD on (measured at C2, us per iteration for all chains:
@@ -733,6 +734,15 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
             m = bundles * cpp;
             a.bundle_slots = xcds;
             a.waves = waves_single > cpp ? waves_single : cpp;   // a leader wave per chain
+            // bundles of 8 on 8 waves, at most 5 panels per group, two panels of K columns in a
+            // wave's registers: the balanced layout (4 chains of panel w % 4 + 1 chain of the
+            // fifth panel per wave instead of 8 chains of one panel on waves 0 .. 3)
+#ifndef BMC_NO_BAL
+            // (panels_per_wave = 1 asked for explicitly keeps the one-panel layout: the A/B knob)
+            a.bundle_bal = (cpp == 8 && a.waves == 8 && geo.ppg <= 5 && K > 8 &&
+                            c->tune.panels_per_wave != 1 &&
+                            bmc::gibbs_reg_capacity(K, a.P.f32 != 0, 2)) ? 1 : 0;
+#endif
             resident = bundles * a.G;
             passes += (int64_t)bundles * iters;
         } else if (cpp_max > 1 && left >= 2) {

@@ -145,6 +145,8 @@ struct GibbsArgs {
     int32_t chains_per_pass;  // > 1: gibbs_multi_kernel, bundles of that many chains
     uint32_t epoch0 = 0;      // nonce of this launch: exchange tags are epoch0 + t + 1, placement
                               // words carry it in their high half (host: never lets a tag be 0)
+    int32_t bundle_bal = 0;   // 1: bundles of 8 in the balanced two-panels-per-wave layout (<= 5 panels
+                              // per group, 8 waves; PanelStore::partial_rss_reg_bal)
     int32_t bundle_slots = 0; // gibbs_multi_kernel: 0 = ONE bundle, grid = G (a chain over the whole
                               // chip); > 0 = grid = bundle_slots x G, bundle b = blockIdx % slots
                               // (one bundle per XCD: chains b * cpp .. b * cpp + cpp - 1), n_chains

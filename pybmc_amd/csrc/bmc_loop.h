@@ -339,8 +339,11 @@ struct PanelStore {
     // share_last (register residency, one panel per wave, several chains per pass): the waves
     // past the group's last panel hold a COPY of that panel, so that its chains can be split
     // among them (gibbs_multi_kernel) instead of one SIMD carrying two whole panels
+    // balanced (register residency, bundles of 8 chains on 8 waves, at most 5 panels per group,
+    // PPW = 2 registers sets): set 0 holds panel wave % 4, set 1 the fifth panel (index 4) --
+    // see partial_rss_reg_bal
     __device__ __forceinline__ void init(const Panels& P, int G_, int g_, T* Xs_, T* ys_,
-                                         bool share_last = false) {
+                                         bool share_last = false, bool balanced = false) {
         keep = P.stream_keep;
         Xg = reinterpret_cast<const T*>(P.X);
         yg = reinterpret_cast<const T*>(P.y);
@@ -360,6 +363,7 @@ struct PanelStore {
             for (int i = 0; i < PPW; ++i) {
                 int q = wave + i * nw;
                 if (share_last && PPW == 1 && npl > 0 && q >= npl) q = npl - 1;
+                if (balanced) q = i == 0 ? (wave & 3) : 4;
                 const bool have = q < npl;
                 const int64_t p = g + (int64_t)q * G;
 #pragma unroll
@@ -540,6 +544,57 @@ struct PanelStore {
                 }
             s[c] = t;
         }
+    }
+
+    // Balanced form of the pass for a bundle of 8 chains on 8 waves (stamps, 64 chains at C2: a
+    // wave alone issues one v_fmac_f64_dpp per ~6.5 cycles, so the wave that owned a whole panel
+    // x 8 chains -- 256 FMAs -- set the length of the pass while its SIMD-mate idled after 64).
+    // Waves w and w + 4 both hold panel w % 4 and take 4 of its 8 chains each; the fifth panel is
+    // held by every wave, one chain each: 4 + 1 (panel, chain) units per wave, 10 per SIMD.
+    // sA[cc] = lane partial of chain 4 * (wave / 4) + cc on panel wave % 4; sB = of chain `wave`
+    // on panel 4.  Per (chain, panel) the operations are those of partial_rss.
+    __device__ __forceinline__ void partial_rss_reg_bal(const double* u, int kpad, double (&sA)[4],
+                                                        double& sB) const {
+        static_assert(MODE == MODE_REG && PPW == 2 && VEC == 1 && KMAX >= 16, "balanced bundles");
+        typedef const __attribute__((address_space(3))) double lds_cd;
+        lds_cd* ub = (lds_cd*)u;
+        constexpr int NU = (KMAX + 15) / 16;
+        const int half = wave >> 2;
+        double urow[5][NU];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int chain = c < 4 ? 4 * half + c : wave;
+#pragma unroll
+            for (int r = 0; r < NU; ++r) urow[c][r] = ub[chain * kpad + r * 16 + (lane & 15)];
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int r = 0; r < NU; ++r) asm volatile("" : "+v"(urow[c][r]));
+        auto one = [&](auto cc) -> double {
+            constexpr int c = decltype(cc)::value;
+            constexpr int i = c < 4 ? 0 : 1;            // register set: own panel, fifth panel
+            double acc[4] = {(double)yr[i][0], 0.0, 0.0, 0.0};
+            if constexpr (sizeof(T) == 8) {
+                static_for<NU>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double xb[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) xb[q] = (double)xr[i][16 * r + q][0];
+                    fmac16_rowbcast_neg(acc, urow[c][r], xb);
+                });
+            } else {
+                static_for<KMAX>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    fmac_rowbcast_neg<j % 16, (j % 16 == 0)>(acc[j % 4], urow[c][j / 16],
+                                                           as_f64_in_loop(xr[i][j][0]));
+                });
+            }
+            const double r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            return fma(r, r, 0.0);
+        };
+        static_for<4>([&](auto cc) { sA[decltype(cc)::value] = one(cc); });
+        sB = one(std::integral_constant<int, 4>{});
     }
 
     // this lane's share of sum (y - X u)^2 over the wave's panels; u_lds zero-padded to 64
@@ -896,6 +951,27 @@ __device__ __forceinline__ double group_allreduce_multi(const double (&s)[CPP], 
     GSTAMP(4);
     return exchange_sum<(CPP >= 4)>(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane, epoch,
                                     local, ok STAMP_ARGS, idle);
+}
+
+// Balanced bundles (partial_rss_reg_bal): rows are written by the caller; this is the leader's
+// half of group_allreduce_multi_lanewise.
+template <int CPP, int TEAMS = -1, typename F = NoIdleWork>
+__device__ __forceinline__ double group_allreduce_multi_prewritten(double* red, gu64* gp_chain0,
+                                                                   size_t chain_stride, int G, int g,
+                                                                   int wave, int lane, unsigned epoch,
+                                                                   bool local, bool& ok STAMP_PARAMS,
+                                                                   F idle = F()) {
+    GSTAMP(3);
+    __syncthreads();
+    ok = true;
+    if (wave >= CPP) return 0.0;
+    const double* r = red + (size_t)wave * 512 + lane;
+    const double r0 = r[0], r1 = r[64], r2 = r[128], r3 = r[192];
+    const double r4 = r[256], r5 = r[320], r6 = r[384], r7 = r[448];
+    const double t = wave_sum(((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)));
+    GSTAMP(4);
+    return exchange_sum<(CPP >= 4), F, TEAMS>(t, gp_chain0 + (size_t)wave * chain_stride, G, g, lane,
+                                             epoch, local, ok STAMP_ARGS, idle);
 }
 
 // The same for register residency with one row per lane, in the lane-wise form of

@@ -372,7 +372,10 @@ void gibbs_loop_kernel(GibbsArgs a) {
 // ======================================================================================
 // SLOTTED: one bundle per XCD slot (bundle_slots > 0), which implies G <= 32: the one-level
 // exchange is known at compile time and the two-level code leaves the loop.
-template <typename T, int VEC, int MODE, int CPP, int KMAX = 0, int PPW = 0, bool SLOTTED = false>
+// BAL: bundles of 8 chains on 8 waves with at most 5 panels per group, two register sets per
+// wave (PPW = 2): the balanced layout of PanelStore::partial_rss_reg_bal.
+template <typename T, int VEC, int MODE, int CPP, int KMAX = 0, int PPW = 0, bool SLOTTED = false,
+          bool BAL = false>
 __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     constexpr int RP = 64 * VEC;
     // lane-chunks of 64 columns: register residency means K <= 64, so one chunk is known at
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
     if (tid == 0) { ctl[1] = 0.0; ctl[2] = 0.0; }
 
     PanelStore<T, VEC, MODE, KMAX, PPW> store;
-    store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y), LANEWISE);
+    store.init(a.P, G, g, reinterpret_cast<T*>(smem + L.x), reinterpret_cast<T*>(smem + L.y),
+               LANEWISE && !BAL, BAL);
     // Which (panel, chains) this wave computes.  Lane-wise form (one panel per wave): wave w < npl
     // owns local panel w; the waves past the last panel hold a copy of it and split its CPP chains
     // with its owner -- C2: 5 panels on a CU's 4 SIMDs, 8 waves: 8 + 2 (panel, chain) units per
@@ -505,7 +509,21 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         double s[CPP];
 #pragma unroll
         for (int c = 0; c < CPP; ++c) s[c] = 0.0;
-        if constexpr (MODE == MODE_REG) store.template partial_rss_reg_multi<CPP>(u_lds, kpad, s, c_lo, c_hi);
+        if constexpr (BAL) {
+            // (rows of the lane-wise sum are indexed by PANEL: set 0 = panel wave % 4, chains
+            // 4 (wave / 4) .. + 3; set 1 = panel 4, chain `wave`)
+            double sA[4], sB;
+            store.partial_rss_reg_bal(u_lds, kpad, sA, sB);
+            const int npl = store.npl, pa = wave & 3, half = wave >> 2;
+            if (pa < npl) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) red[((4 * half + cc) * 8 + pa) * 64 + lane] = sA[cc];
+            }
+            if (npl > 4) red[(wave * 8 + 4) * 64 + lane] = sB;
+            s[CPP - 1] = sB;   // (ties the abort test below to the end of the pass)
+        } else if constexpr (MODE == MODE_REG) {
+            store.template partial_rss_reg_multi<CPP>(u_lds, kpad, s, c_lo, c_hi);
+        }
         for (int q = store.wave; MODE != MODE_REG && q < store.npl; q += store.nw) {
             if constexpr (MODE == MODE_LDS) {
                 panel_rss_multi<T, VEC, CPP>(store.Xs + (size_t)q * K * RP + lane * VEC,
@@ -557,7 +575,11 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
             }
         };
         double rss;
-        if constexpr (LANEWISE)
+        if constexpr (BAL)
+            rss = group_allreduce_multi_prewritten<CPP, (SLOTTED ? 0 : -1)>(
+                red, gran0 + (size_t)(t & 1) * a.gran_stride, chain_stride, G, g, wave, lane, epoch,
+                local, got STAMP_ARGS, record);
+        else if constexpr (LANEWISE)
             rss = group_allreduce_multi_lanewise<CPP, (SLOTTED ? 0 : -1)>(
                 s, red, row, c_lo, c_hi, gran0 + (size_t)(t & 1) * a.gran_stride, chain_stride, G, g,
                 wave, lane, epoch, local, got STAMP_ARGS, record);
@@ -1037,6 +1059,13 @@ static hipError_t launch_multi_reg_k(const GibbsArgs& a, hipStream_t s) {
     const size_t lds = gibbs_lds_bytes(a);
 #define BMC_MR(C)                                                                            \
     do {                                                                                         \
+        if constexpr (VEC == 1 && C == 8 && KMAX >= 16 && KMAX * sizeof(T) <= 256) {             \
+            if (a.bundle_slots > 0 && a.bundle_bal)                                              \
+                return launch_or_query(                                                          \
+                    (const void*)gibbs_multi_kernel<T, VEC, MODE_REG, C, KMAX, 2, true, true>,     \
+                    dim3(a.bundle_slots * a.G), dim3(64 * a.waves), lds, s, a, a.query_occupancy); \
+        }                                                                                        \
+        if (a.bundle_bal) return hipErrorInvalidValue;                                           \
         if constexpr (VEC == 1) {                                                                \
             if (a.bundle_slots > 0)                                                              \
                 return launch_or_query(                                                          \

@@ -536,6 +536,35 @@ def test_bundles_of_chains_per_xcd(nch, cpp, launches, ask):
     assert np.array_equal(off, out[:min(nch, 20)])
 
 
+@pytest.mark.parametrize("n,k,dt", [(10000, 32, np.float64), (9000, 16, np.float32), (5000, 20, np.float64),
+                                    (8000, 32, np.float32), (10100, 16, np.float64)])
+def test_bundles_of_eight_balanced_and_one_panel_layouts_agree(n, k, dt):
+    """Bundles of 8 chains with at most 5 panels per workgroup run in the balanced layout (every
+    wave holds two panels: 4 chains of panel w % 4 and one chain of the fifth,
+    PanelStore::partial_rss_reg_bal); panels_per_wave = 1 keeps the one-panel-per-wave layout.
+    Both must give the same bits (the lane-wise group sum is indexed by panel in both), ragged
+    last groups included (N = 5000: 3 panels at most; N = 10100: the last group has fewer)."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(3 * n + k)
+    X = (rng.standard_normal((n, k)) / np.sqrt(n)).astype(dt)
+    y = (X.astype(np.float64) @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)).astype(dt)
+    ctx.set_problem(y, np.asfortranarray(X), dtype=dt)
+    ctx.set_prior(np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+    T, nch = 250, 64
+    seeds = np.arange(nch) + 5
+    bal, st = ctx.gibbs_run(nch, T, seeds=seeds)
+    ctx.set_tuning(panels_per_wave=1)
+    one, st1 = ctx.gibbs_run(nch, T, seeds=seeds)
+    ctx.set_tuning()
+    for s_ in (st, st1):
+        assert s_["residency"] == 1 and s_["chains_per_pass"] == 8 and s_["launches"] == 1, s_
+    assert st["groups_per_chain"] == st1["groups_per_chain"]
+    assert np.isfinite(bal).all()
+    assert np.array_equal(bal, one)
+    solo, _ = ctx.gibbs_run(1, T, seeds=seeds[41:42])
+    assert np.array_equal(bal[41], solo[0])
+
+
 @pytest.mark.parametrize("n,k,dt", [(10000, 8, np.float64), (10000, 64, np.float64), (9000, 16, np.float32),
                                     (12000, 64, np.float32), (5000, 20, np.float64)])
 def test_bundles_other_widths_and_storage(n, k, dt):
