@@ -331,9 +331,16 @@ int rss_on_raw(bmc_ctx* c, const double* coef_host, int32_t nb, double* out_host
 
 struct Geometry {
     int chains_per_launch, G, waves, ppg, mode, ppw, nslot;
+    int one_wave;   // the chain runs in ONE wave (gibbs_wave_kernel)
 };
 
 constexpr int RES_AUTO = 0, RES_REG = 1, RES_STREAM = 3;  // 2 = LDS
+// one-wave chains: register-resident FMAs per iteration (rows per lane x columns, padded) up to
+// which one wave beats the workgroup form.  Same-box, us per iteration, wave / workgroup:
+// 12 x 4 (N = 629, K = 3) 0.351 / 0.629, 16 x 4 0.394 / 0.636, 12 x 8 0.469 / 0.633,
+// 2 x 32 0.521 / 0.545; 16 x 8 0.675 / 0.636, 8 x 16 0.657 / 0.562, 4 x 32 0.739 / 0.550
+// (gpurun_out/r3_wave_ab3.log)
+constexpr int ONE_WAVE_MAX_FMAS = 96;
 // Chip shape from the device properties (MI355X in SPX mode: 256 CUs = 8 XCDs x 32; a
 // partitioned device exposes fewer CUs, and the co-residency bound must follow it).
 struct Chip {
@@ -356,7 +363,7 @@ Chip chip_of(const bmc_ctx* c) {
 
 // Pick the launch geometry.  Preference order: row panels in VGPRs with each chain on
 // one XCD (8 slots x <= 32 groups), then panels pinned in LDS, then streaming.
-Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
+Geometry choose_geometry(const bmc_ctx* c, int n_chains, bool allow_one_wave = false) {
     const Chip chip = chip_of(c);
     const int MAX_GROUPS_PER_LAUNCH = chip.groups_max, XCD_COUNT = chip.xcds,
               CU_PER_XCD = chip.cu_per_xcd;
@@ -378,6 +385,25 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains) {
     // No inter-workgroup exchange, no co-residency requirement (measured 0.85 us/iteration at
     // N = 629 against 1.4 with ten single-wave groups), and every chain is an independent
     // workgroup, so hundreds of chains run side by side in one launch.
+    // Smaller still (the reference's data set, 629 x 3): the chain in ONE wave, rows and columns
+    // in its registers, no hand-over of any kind inside an iteration (gibbs_wave_kernel; measured
+    // at N = 629, K = 3: see DESIGN.md 4.1).  waves_per_group = 1 asks for it, > 1 or an
+    // explicit panels_per_wave keep the workgroup form.
+    if (allow_one_wave && (tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec == 1 &&
+        tu.groups_per_chain <= 1 && tu.waves_per_group <= 1 && tu.panels_per_wave <= 0) {
+        const int fmas = bmc::gibbs_wave_capacity(c->k, (int)NP);
+        if (fmas > 0 && (fmas <= ONE_WAVE_MAX_FMAS || tu.waves_per_group == 1)) {
+            g.mode = 0;
+            g.ppw = (int)NP;
+            g.G = 1;
+            g.waves = 1;
+            g.ppg = (int)NP;
+            g.chains_per_launch = n_chains < 2048 ? n_chains : 2048;
+            g.nslot = g.chains_per_launch;
+            g.one_wave = 1;
+            return g;
+        }
+    }
     if ((tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec == 1 &&
         tu.groups_per_chain <= 1) {
         for (int want : {4, 8}) {
@@ -575,7 +601,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         d_samples = (double*)c->samples.p;
     }
     if ((rc = check_tuning_fits(c))) return rc;
-    Geometry geo = choose_geometry(c, n_chains);
+    Geometry geo = choose_geometry(c, n_chains, true);
     // One-XCD register residency with more than 8 chains.
     // (a) 16 chains or more: the register-resident panels of an XCD's 32 groups serve a BUNDLE of
     //     2 / 4 / 8 chains per pass (gibbs_multi_kernel, one bundle per XCD: 16 .. 64 chains in one
@@ -653,6 +679,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
     a.nslot = geo.nslot;
     a.force_agent_scope = c->tune.force_agent_scope;
     a.panels_per_group = geo.ppg;
+    a.one_wave = geo.one_wave;
     if (geo.mode == 2) {
         // A matrix larger than the 256 MiB Infinity Cache, swept once per iteration, would evict
         // itself before it is read again.  Each group then reads its first panels normally, about

@@ -158,6 +158,7 @@ struct GibbsArgs {
                             // VGPR count of the packed (<= 128 VGPR) variant of the kernel it
                             // would have launched, 0 if that shape has none
     int32_t pack;           // 1: launch the packed variant (two chains per XCD)
+    int32_t one_wave = 0;   // 1: gibbs_wave_kernel, one wave per chain (gibbs_wave_capacity() > 0)
     int32_t* query_occupancy = nullptr;  // host pointer; when set launch_gibbs launches nothing and
                             // reports how many workgroups of the kernel / block size / LDS bytes it
                             // would have launched ONE CU admits (hipOccupancyMaxActiveBlocksPer
@@ -181,6 +182,9 @@ struct GramArgs {
     int32_t n_chains;
 };
 hipError_t launch_gibbs_gram(const GramArgs& a, hipStream_t s);
+// register-resident FMAs per iteration of the one-wave-per-chain kernel for k columns and
+// npanels panels of 64 rows (f64 or f32 storage, one row per lane), 0 = no such kernel
+int gibbs_wave_capacity(int k, int npanels);
 
 struct SimplexArgs {
     Panels P;               // UN-rotated panels (the simplex sampler proposes beta itself)

@@ -679,6 +679,100 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
     if (lane == 0 && T_it > 0) uout[(T_it - 1) * (K + 1) + K] = sqrt(sp_eff / g_eff);
 }
 
+// ======================================================================================
+// A chain small enough for ONE wave (the reference's own data set: 629 rows, 3 kept components;
+// SURVEY 8, configuration C1): lane l keeps rows l, 64 + l, 128 + l, .. of the rotated matrix in
+// registers, RMAX rows x KMAX columns, and the whole iteration runs in that wave -- u goes from
+// the lanes that draw it to the FMAs through v_readlane (SGPR operands), the residual sum is
+// one wave_sum; no LDS, no barrier, no exchange, nothing to wait for.  The workgroup form of
+// the same chain (gibbs_loop_kernel<.., SINGLE>: 5 waves, two barriers, u and the lane
+// partials through LDS) spends ~1340 cycles per iteration at N = 629, K = 3, nearly all of it
+// hand-over latency.  Any number of chains per launch, one wave each.
+// The draw and the sigma2 step are those of gibbs_loop_kernel; per row the residual is the
+// chain acc = y, acc = fma(-x_j, u_j, acc), j ascending, rows summed into two accumulators.
+// ======================================================================================
+template <typename T, int RMAX, int KMAX>
+__global__ __launch_bounds__(64) void gibbs_wave_kernel(GibbsArgs a) {
+    // 64 output rows [u_t, sigma_t] staged here and written out together (below)
+    __shared__ double rows[64 * (KMAX + 1)];
+    const int lane = threadIdx.x, K = a.P.k, NP = a.P.npanels;
+    const int chain = blockIdx.x;
+    if (chain >= a.n_chains) return;
+    const int64_t T_it = a.iters;
+    const double* xi = a.xi + (int64_t)chain * T_it * K;
+    const double* gam = a.gam + (int64_t)chain * T_it;
+    double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
+    const T* Xp = reinterpret_cast<const T*>(a.P.X);
+    const T* yp = reinterpret_cast<const T*>(a.P.y);
+    double x[RMAX][KMAX], y[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            x[r][j] = (r < NP && j < K) ? (double)Xp[((size_t)r * K + j) * 64 + lane] : 0.0;
+        y[r] = r < NP ? (double)yp[(size_t)r * 64 + lane] : 0.0;
+    }
+    const bool act = lane < K;
+    // (lanes K .. 63: lam = c1 = c2 = xi = 0 draw u = 0 -- no exec-mask region around the draw)
+    const double lam = act ? a.lam[lane] : 0.0, c1 = act ? a.c1[lane] : 0.0;
+    const double c2 = act ? a.c2[lane] : 0.0;
+    if (lane == 0) a.placement[chain] = 1;
+    double sp_eff = a.sigma2_init, g_eff = 1.0;
+    double sp_cap = 1.0, g_cap = 1.0;   // lane i: the (sp, g) pair behind staged row i
+    double xi_next = (act && T_it > 0) ? xi[lane] : 0.0;
+    double gam_next = T_it > 0 ? gam[0] : 1.0;
+    const int K1 = K + 1;
+    // every load issued so far is complete from here on, and hipcc knows it: merged with the
+    // loop's own state its wait in front of the first FMA was vmcnt(1) -- behind the prefetch
+    // just issued, a memory latency per iteration (see gibbs_loop_kernel)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    for (int64_t t = 0; t < T_it; ++t) {
+        const int slot = (int)(t & 63);
+        const double u = draw_u(lam, c1, c2, xi_next, sp_eff, g_eff, 0.0);
+        const double gam_t = gam_next;
+        {   // next iteration's variates (clamped index: no branch around the loads)
+            const int64_t tn = t + 1 < T_it ? t + 1 : t;
+            xi_next = act ? xi[tn * K + lane] : 0.0;
+            gam_next = gam[tn];
+        }
+        if (act) rows[slot * K1 + lane] = u;
+        double uj[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) uj[j] = readlane_f64(u, j);
+        double part0 = 0.0, part1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            double acc = y[r];
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) acc = fma(-x[r][j], uj[j], acc);
+            if (r & 1) part1 = fma(acc, acc, part1);
+            else part0 = fma(acc, acc, part0);
+        }
+        const double rss = wave_sum(part0 + part1);
+        // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
+        const double scale_post = (a.nu0_s20 + rss) * 0.5;
+        const bool floor_hit = scale_post < 1e-6 * gam_t;
+        sp_eff = floor_hit ? 1e-6 : scale_post;
+        g_eff = floor_hit ? 1.0 : gam_t;
+        // The recorded sigma_t = sqrt(sp / g) is a correctly rounded division and square root,
+        // ~35 dependent f64 operations that nothing in this wave can hide.  Lane (t mod 64)
+        // keeps the pair instead, and every 64 iterations all lanes take their roots at once
+        // and the 64 staged rows go out as contiguous stores -- the loop itself then has no
+        // store in flight, so its waits for the prefetched variates are exact.  (First version,
+        // sqrt and stores in the loop: 0.49 us per iteration at N = 629, K = 3.)
+        const bool mine = lane == slot;
+        sp_cap = mine ? sp_eff : sp_cap;
+        g_cap = mine ? g_eff : g_cap;
+        if (slot == 63 || t + 1 == T_it) {
+            const int nrows = slot + 1;
+            const double sig = sqrt(sp_cap / g_cap);
+            if (lane < nrows) rows[lane * K1 + K] = sig;
+            double* dst = uout + (t - slot) * K1;
+            for (int idx = lane; idx < nrows * K1; idx += 64) dst[idx] = rows[idx];
+        }
+    }
+}
+
 hipError_t launch_gibbs_gram(const GramArgs& a, hipStream_t s) {
     if (a.k < 1 || a.k > 64 || a.n_chains < 1) return hipErrorInvalidValue;
     const dim3 grid((unsigned)a.n_chains), block(64);
@@ -1106,7 +1200,48 @@ static hipError_t launch_multi_reg(const GibbsArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// row panels x columns a wave keeps: RMAX * KMAX <= 128 (and at most 16 panels = 1024 rows)
+static constexpr int wave_kmax(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 0; }
+static constexpr int wave_rmax(int np) { return np <= 2 ? 2 : np <= 4 ? 4 : np <= 8 ? 8 : np <= 12 ? 12 : np <= 16 ? 16 : 0; }
+int gibbs_wave_capacity(int k, int npanels) {
+    const int km = wave_kmax(k), rm = wave_rmax(npanels);
+    return (km > 0 && rm > 0 && km * rm <= 128) ? km * rm : 0;
+}
+
+template <typename T, int RMAX>
+static hipError_t launch_wave_r(const GibbsArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)a.n_chains), block(64);
+#define BMC_WV(KM)                                                                              \
+    if constexpr (RMAX * KM <= 128)                                                             \
+        return launch_or_query((const void*)gibbs_wave_kernel<T, RMAX, KM>, grid, block, 0, s, a, \
+                               a.query_occupancy);                                              \
+    break
+    switch (wave_kmax(a.P.k)) {
+        case 4: BMC_WV(4);
+        case 8: BMC_WV(8);
+        case 16: BMC_WV(16);
+        case 32: BMC_WV(32);
+    }
+#undef BMC_WV
+    return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t launch_wave(const GibbsArgs& a, hipStream_t s) {
+    if (a.query_regs || a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, a.P.npanels) || a.n_chains < 1)
+        return hipErrorInvalidValue;
+    switch (wave_rmax(a.P.npanels)) {
+        case 2: return launch_wave_r<T, 2>(a, s);
+        case 4: return launch_wave_r<T, 4>(a, s);
+        case 8: return launch_wave_r<T, 8>(a, s);
+        case 12: return launch_wave_r<T, 12>(a, s);
+        case 16: return launch_wave_r<T, 16>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
+    if (a.one_wave) return a.P.f32 ? launch_wave<float>(a, s) : launch_wave<double>(a, s);
     if (a.chains_per_pass > 1) {
         if (a.query_regs) return hipErrorInvalidValue;
         // bundles of chains_per_pass chains (one, or one per slot); a leader wave per chain

@@ -225,6 +225,55 @@ def test_small_problem_runs_in_one_workgroup_per_chain():
         assert np.abs(many[c] - multi[i]).max() < 1e-11
 
 
+@pytest.mark.parametrize("n,k,dt", [(629, 3, np.float64), (64, 1, np.float64), (100, 4, np.float64),
+                                    (1000, 4, np.float64), (700, 8, np.float64), (500, 16, np.float64),
+                                    (250, 32, np.float64), (1024, 8, np.float64), (629, 3, np.float32),
+                                    (300, 13, np.float32)])
+def test_one_wave_chains(n, k, dt):
+    """A chain of a few hundred rows and a few columns runs in ONE wave (gibbs_wave_kernel: rows
+    and columns in the wave's registers, no LDS hand-over, no barrier; output rows staged 64 at
+    a time).  Every register shape (rows per lane x columns), both storage types: equal to the
+    one-workgroup form to rounding, independent of how many chains share the launch, for
+    iteration counts around the 64-row staging block, and equal to the replayed oracle chain."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(7 * n + k)
+    X = (rng.standard_normal((n, k)) / np.sqrt(n)).astype(dt)
+    y = (X.astype(np.float64) @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)).astype(dt)
+    prior = (np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+    ctx.set_problem(y, np.asfortranarray(X), dtype=dt)
+    ctx.set_prior(*prior)
+    seeds = np.arange(70) + 3
+    ctx.set_tuning(waves_per_group=1)
+    for T in (1, 63, 64, 65, 130):
+        many, st = ctx.gibbs_run(70, T, seeds=seeds)
+        assert st["waves_per_group"] == 1 and st["groups_per_chain"] == 1 and st["launches"] == 1, st
+        assert st["xcd_local_chains"] == 70 and np.isfinite(many).all()
+        solo, _ = ctx.gibbs_run(1, T, seeds=seeds[33:34])
+        assert np.array_equal(many[33], solo[0]), T
+        if T > 1:   # (a prefix of a longer run: the variates of iteration t do not depend on T)
+            assert np.array_equal(many[33][:1], ctx.gibbs_run(1, 1, seeds=seeds[33:34])[0][0])
+    ctx.set_tuning(waves_per_group=4, groups_per_chain=1)
+    group, stg = ctx.gibbs_run(3, 130, seeds=seeds[[0, 33, 69]])
+    ctx.set_tuning()
+    assert stg["waves_per_group"] == 4 and stg["groups_per_chain"] == 1
+    scale = max(1.0, np.abs(group).max())
+    for i, c in enumerate((0, 33, 69)):
+        assert np.abs(many[c] - group[i]).max() < 1e-11 * scale, c
+    if dt == np.float64:
+        Xd = X.astype(np.float64)
+        st_o = O.chain_setup(y, Xd, prior)
+        Z, G = O.reference_streams(11, 12, 70, k, O.gamma_shape(st_o))
+        ref, trace = O.gibbs_replay(y, Xd, 70, prior, Z, G, return_sigma2=True)
+        W, lam, _ = ctx.basis()
+        xi = O.innovations_in_basis(st_o, y, Xd, ref, W, lam, trace)
+        ctx.set_tuning(waves_per_group=1)
+        out, st = ctx.gibbs_run(2, 70, xi=np.repeat(xi[None], 2, 0), g=np.repeat(G[None], 2, 0))
+        ctx.set_tuning()
+        assert st["waves_per_group"] == 1
+        assert np.array_equal(out[0], out[1])
+        assert np.abs(out[0] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
 # ---------------------------------------------------------------- edge cases
 def test_edge_shapes():
     ctx = gpu_ctx()
