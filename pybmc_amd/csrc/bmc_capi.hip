@@ -1395,7 +1395,7 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     std::vector<double> step(K);
     for (int j = 0; j < K; ++j) step[j] = std::sqrt(S_hat[j] * S_hat[j] * stepsize * stepsize);  // :80
     if ((rc = check_tuning_fits(c))) return rc;
-    const Geometry geo = choose_geometry(c, 1);
+    const Geometry geo = choose_geometry(c, 1, Km <= 64);   // (one wave: a model per lane)
     const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)3 * gran_stride * 8))) return rc;
     HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)3 * gran_stride * 8, c->stream));
@@ -1449,6 +1449,7 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     a.nslot = geo.nslot;
     a.force_agent_scope = c->tune.force_agent_scope;
     a.panels_per_group = geo.ppg;
+    a.one_wave = geo.one_wave;
     a.epoch0 = launch_nonce(c, (uint64_t)Tt);
     if (a.vt_in_lds && simplex_lds_bytes(a) > LDS_LIMIT) a.vt_in_lds = 0;
     if (simplex_lds_bytes(a) > LDS_LIMIT) return fail(c, BMC_EINVAL, "LDS plan exceeds 160 KiB");

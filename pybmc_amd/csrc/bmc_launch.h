@@ -208,6 +208,7 @@ struct SimplexArgs {
     int32_t G, waves, mode, reg_ppw, nslot, force_agent_scope, panels_per_group;
     uint32_t epoch0 = 0;    // as in GibbsArgs
     int32_t* query_occupancy = nullptr;  // as in GibbsArgs
+    int32_t one_wave = 0;   // 1: simplex_wave_kernel (gibbs_wave_capacity() > 0, Km <= 64)
 };
 size_t simplex_lds_bytes(const SimplexArgs& a);
 hipError_t launch_simplex(const SimplexArgs& a, hipStream_t s);

@@ -1200,6 +1200,108 @@ static hipError_t launch_multi_reg(const GibbsArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// The simplex-constrained sampler in the same one-wave form (simplex_loop_kernel's steps: the
+// proposal, the simplex test of its weights, the residual sum of an inside proposal, the
+// Metropolis test, the sigma2 draw), at most 64 models: lane m keeps column m of Vt_hat.  The
+// kept rows [beta_t, sigma_t] are staged 64 at a time as in gibbs_wave_kernel.
+template <typename T, int RMAX, int KMAX>
+__global__ __launch_bounds__(64) void simplex_wave_kernel(SimplexArgs a) {
+    __shared__ double rows[64 * (KMAX + 1)];
+    const int lane = threadIdx.x, K = a.P.k, NP = a.P.npanels, Km = a.Km;
+    if (blockIdx.x != 0) return;
+    const int64_t T_tot = a.burn + a.iters;
+    const T* Xp = reinterpret_cast<const T*>(a.P.X);
+    const T* yp = reinterpret_cast<const T*>(a.P.y);
+    double x[RMAX][KMAX], y[RMAX], vtr[KMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            x[r][j] = (r < NP && j < K) ? (double)Xp[((size_t)r * K + j) * 64 + lane] : 0.0;
+        y[r] = r < NP ? (double)yp[(size_t)r * 64 + lane] : 0.0;
+    }
+    const bool act = lane < K, model = lane < Km;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) vtr[j] = (j < K && model) ? a.Vt[(size_t)j * Km + lane] : 0.0;
+    const double step = act ? a.step[lane] : 0.0;
+    if (lane == 0) a.placement[0] = 1;
+    double b_cur = 0.0;                                 // :82
+    double rss_cur = a.rss_init;                        // -log_likelihood_current (:85)
+    double s2 = a.rss_init / (double)a.P.n;             // :86
+    double s2_cap = 1.0;                                // lane i: sigma2 behind staged row i
+    double xi_next = (act && T_tot > 0) ? a.xi[lane] : 0.0;
+    double gam_next = T_tot > 0 ? a.gam[0] : 1.0;
+    double unif_next = a.n_unif > 0 ? a.unif[0] : 0.5;
+    int64_t iu = 0, accepted = 0;
+    const double w0 = 1.0 / (double)Km;
+    const int K1 = K + 1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see gibbs_wave_kernel
+    for (int64_t t = 0; t < T_tot; ++t) {
+        // proposal b_cur + diag(S_hat stepsize) xi  (:98,:121); lanes K .. 63 stay 0
+        const double b_prop = fma(step, xi_next, b_cur);
+        const double gam_t = gam_next;
+        {
+            const int64_t tn = t + 1 < T_tot ? t + 1 : t;
+            xi_next = act ? a.xi[tn * K + lane] : 0.0;
+            gam_next = a.gam[tn];
+        }
+        double uj[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) uj[j] = readlane_f64(b_prop, j);
+        // omegas = b_prop Vt_hat + 1/Km >= 0 ?                          (:99-102)
+        double o[4] = {w0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) o[j & 3] = fma(uj[j], vtr[j], o[j & 3]);
+        const bool neg = model && ((o[0] + o[1]) + (o[2] + o[3]) < 0.0);
+        if (!__any(neg)) {
+            double part0 = 0.0, part1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                double acc = y[r];
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) acc = fma(-x[r][j], uj[j], acc);
+                if (r & 1) part1 = fma(acc, acc, part1);
+                else part0 = fma(acc, acc, part0);
+            }
+            const double rss_prop = wave_sum(part0 + part1);
+            if (iu >= a.n_unif) {
+                if (lane == 0) a.status[0] = 2;
+                break;
+            }
+            // min(1, exp((ll_prop - ll_cur) / sigma2)), ll = -rss     (:106-109)
+            const double ratio = exp((rss_cur - rss_prop) / s2);
+            const double p_acc = ratio < 1.0 ? ratio : 1.0;
+            const double uu = unif_next;
+            ++iu;
+            if (iu < a.n_unif) unif_next = a.unif[iu];
+            if (uu < p_acc) {                                          // :110-112
+                b_cur = b_prop;
+                rss_cur = rss_prop;
+                if (t >= a.burn) ++accepted;
+            }
+        }
+        // sigma2 = 1 / Gamma(shape, 1/scale_post), no floor on this path      (:115-117)
+        s2 = ((a.nu0_s20 + rss_cur) * 0.5) / gam_t;
+        if (t >= a.burn) {
+            const int64_t kept = t - a.burn;
+            const int slot = (int)(kept & 63);
+            if (act) rows[slot * K1 + lane] = b_cur;
+            s2_cap = lane == slot ? s2 : s2_cap;
+            if (slot == 63 || t + 1 == T_tot) {
+                const int nrows = slot + 1;
+                const double sig = sqrt(s2_cap);
+                if (lane < nrows) rows[lane * K1 + K] = sig;
+                double* dst = a.out + (kept - slot) * K1;
+                for (int idx = lane; idx < nrows * K1; idx += 64) dst[idx] = rows[idx];
+            }
+        }
+    }
+    if (lane == 0) {
+        a.counters[0] = accepted;
+        a.counters[1] = iu;
+    }
+}
+
 // row panels x columns a wave keeps: RMAX * KMAX <= 128 (and at most 16 panels = 1024 rows)
 static constexpr int wave_kmax(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 0; }
 static constexpr int wave_rmax(int np) { return np <= 2 ? 2 : np <= 4 ? 4 : np <= 8 ? 8 : np <= 12 ? 12 : np <= 16 ? 16 : 0; }
@@ -1208,12 +1310,17 @@ int gibbs_wave_capacity(int k, int npanels) {
     return (km > 0 && rm > 0 && km * rm <= 128) ? km * rm : 0;
 }
 
-template <typename T, int RMAX>
-static hipError_t launch_wave_r(const GibbsArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)a.n_chains), block(64);
+template <typename T, int RMAX, int KM>
+static const void* wave_kernel_of(GibbsTag) { return (const void*)gibbs_wave_kernel<T, RMAX, KM>; }
+template <typename T, int RMAX, int KM>
+static const void* wave_kernel_of(SimplexTag) { return (const void*)simplex_wave_kernel<T, RMAX, KM>; }
+
+template <typename Tag, typename T, int RMAX, typename Args>
+static hipError_t launch_wave_r(const Args& a, int n_blocks, hipStream_t s) {
+    const dim3 grid((unsigned)n_blocks), block(64);
 #define BMC_WV(KM)                                                                              \
     if constexpr (RMAX * KM <= 128)                                                             \
-        return launch_or_query((const void*)gibbs_wave_kernel<T, RMAX, KM>, grid, block, 0, s, a, \
+        return launch_or_query(wave_kernel_of<T, RMAX, KM>(Tag{}), grid, block, 0, s, a,        \
                                a.query_occupancy);                                              \
     break
     switch (wave_kmax(a.P.k)) {
@@ -1226,22 +1333,26 @@ static hipError_t launch_wave_r(const GibbsArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-template <typename T>
-static hipError_t launch_wave(const GibbsArgs& a, hipStream_t s) {
-    if (a.query_regs || a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, a.P.npanels) || a.n_chains < 1)
+template <typename Tag, typename T, typename Args>
+static hipError_t launch_wave(const Args& a, int n_blocks, hipStream_t s) {
+    if (a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, a.P.npanels) || n_blocks < 1)
         return hipErrorInvalidValue;
     switch (wave_rmax(a.P.npanels)) {
-        case 2: return launch_wave_r<T, 2>(a, s);
-        case 4: return launch_wave_r<T, 4>(a, s);
-        case 8: return launch_wave_r<T, 8>(a, s);
-        case 12: return launch_wave_r<T, 12>(a, s);
-        case 16: return launch_wave_r<T, 16>(a, s);
+        case 2: return launch_wave_r<Tag, T, 2>(a, n_blocks, s);
+        case 4: return launch_wave_r<Tag, T, 4>(a, n_blocks, s);
+        case 8: return launch_wave_r<Tag, T, 8>(a, n_blocks, s);
+        case 12: return launch_wave_r<Tag, T, 12>(a, n_blocks, s);
+        case 16: return launch_wave_r<Tag, T, 16>(a, n_blocks, s);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
-    if (a.one_wave) return a.P.f32 ? launch_wave<float>(a, s) : launch_wave<double>(a, s);
+    if (a.one_wave) {
+        if (a.query_regs) return hipErrorInvalidValue;
+        return a.P.f32 ? launch_wave<GibbsTag, float>(a, a.n_chains, s)
+                       : launch_wave<GibbsTag, double>(a, a.n_chains, s);
+    }
     if (a.chains_per_pass > 1) {
         if (a.query_regs) return hipErrorInvalidValue;
         // bundles of chains_per_pass chains (one, or one per slot); a leader wave per chain
@@ -1260,6 +1371,10 @@ hipError_t launch_gibbs(const GibbsArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_simplex(const SimplexArgs& a, hipStream_t s) {
+    if (a.one_wave) {
+        if (a.Km < 1 || a.Km > 64) return hipErrorInvalidValue;
+        return a.P.f32 ? launch_wave<SimplexTag, float>(a, 1, s) : launch_wave<SimplexTag, double>(a, 1, s);
+    }
     if (!geometry_ok(a) || a.Km < 1) return hipErrorInvalidValue;
     return a.P.f32 ? launch_t<SimplexTag, SimplexArgs, float>(a, s)
                    : launch_t<SimplexTag, SimplexArgs, double>(a, s);

@@ -47,6 +47,17 @@ def test_replay_matches_the_reference(name):
         xi=xi, unif=g["uniforms"], g=g["G"], return_stats=True)
     assert np.abs(out - g["samples"]).max() < 1e-9
     assert accepted == acc and used_dev == used == len(g["uniforms"])
+    # sizes like the reference's run in ONE wave (simplex_wave_kernel); the workgroup form gives
+    # the same chain (kept rows are staged 64 at a time: T is not a multiple of 64 here)
+    assert st["waves_per_group"] == 1 and st["groups_per_chain"] == 1, st
+    ctx.set_tuning(groups_per_chain=1, waves_per_group=2)
+    out2, accepted2, used2, st2 = ctx.simplex_run(
+        g["Vt_hat"], g["S_hat"], T, float(g["nu0"]), float(g["s20"]), burn, float(g["stepsize"]),
+        xi=xi, unif=g["uniforms"], g=g["G"], return_stats=True)
+    ctx.set_tuning()
+    assert st2["waves_per_group"] == 2
+    assert accepted2 == accepted and used2 == used_dev
+    assert np.abs(out2 - out).max() < 1e-12
 
 
 def test_replay_is_geometry_independent():
@@ -54,7 +65,8 @@ def test_replay_is_geometry_independent():
     ctx = gpu_ctx()
     burn, T, xi, acc, used = replay_inputs(g)
     ctx.set_problem(g["y"], g["X"])
-    for G, W, res, ppw, agent in [(1, 3, 1, 1, 0), (3, 1, 1, 1, 1), (2, 2, 2, 0, 0), (1, 4, 3, 0, 0)]:
+    for G, W, res, ppw, agent in [(1, 3, 1, 1, 0), (3, 1, 1, 1, 1), (2, 2, 2, 0, 0), (1, 4, 3, 0, 0),
+                                  (1, 1, 0, 0, 0)]:
         ctx.set_tuning(G, W, res, ppw, agent)
         out, accepted = ctx.simplex_run(g["Vt_hat"], g["S_hat"], T, float(g["nu0"]), float(g["s20"]),
                                         burn, float(g["stepsize"]), xi=xi, unif=g["uniforms"], g=g["G"])
