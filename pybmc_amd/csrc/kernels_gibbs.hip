@@ -624,6 +624,9 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
 template <int KMAX>
 __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
     __shared__ double d_lds[64];
+    // 64 output rows [u_t, sigma_t] staged here and written out together (see gibbs_wave_kernel:
+    // the correctly rounded sqrt(sp / g) of every row and the stores leave the loop)
+    __shared__ double rows[64 * (KMAX + 1)];
     const int lane = threadIdx.x, K = a.k;
     const int chain = blockIdx.x;
     if (chain >= a.n_chains) return;
@@ -640,18 +643,22 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
     const double g0x2 = act ? 2.0 * a.g0[lane] : 0.0;
     d_lds[lane] = 0.0;
     double sp_eff = a.sigma2_init, g_eff = 1.0, sq_sp = BMC_SQRT_OF(a.sigma2_init);
+    double sp_cap = 1.0, g_cap = 1.0;   // lane i: the (sp, g) pair behind staged row i
     double xi_next = (act && T_it > 0) ? xi[lane] : 0.0;
     double gam_next = T_it > 0 ? gam[0] : 1.0;
+    const int K1 = K + 1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see gibbs_wave_kernel
     for (int64_t t = 0; t < T_it; ++t) {
-        // u | sigma2, the operations of gibbs_loop_kernel
-        double u = 0.0;
-        if (act) u = draw_u(lam, c1, c2, xi_next, sp_eff, g_eff, sq_sp);
-        const double sp_rec = sp_eff, g_rec = g_eff;
+        const int slot = (int)(t & 63);
+        // u | sigma2, the operations of gibbs_loop_kernel (lanes K .. 63: all inputs 0, u = 0)
+        const double u = draw_u(lam, c1, c2, xi_next, sp_eff, g_eff, sq_sp);
         const double gam_t = gam_next;
-        if (t + 1 < T_it) {
-            if (act) xi_next = xi[(t + 1) * K + lane];
-            gam_next = gam[t + 1];
+        {
+            const int64_t tn = t + 1 < T_it ? t + 1 : t;
+            xi_next = act ? xi[tn * K + lane] : 0.0;
+            gam_next = gam[tn];
         }
+        if (act) rows[slot * K1 + lane] = u;
         // d -> every lane (same wave: the LDS executes its writes and reads in order)
         const double d = u - u0;
         d_lds[lane] = d;
@@ -667,16 +674,23 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
         const double q = wave_sum(d * (gd - g0x2));
         double rss = a.rss0 + q;
         rss = rss > 0.0 ? rss : 0.0;
-        if (act) uout[t * (K + 1) + lane] = u;
-        if (lane == 0 && t > 0) uout[(t - 1) * (K + 1) + K] = sqrt(sp_rec / g_rec);
         // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
         const double scale_post = (a.nu0_s20 + rss) * 0.5;
         const bool floor_hit = scale_post < 1e-6 * gam_t;
         sp_eff = floor_hit ? 1e-6 : scale_post;
         g_eff = floor_hit ? 1.0 : gam_t;
         sq_sp = BMC_SQRT_OF(sp_eff);
+        const bool mine = lane == slot;
+        sp_cap = mine ? sp_eff : sp_cap;
+        g_cap = mine ? g_eff : g_cap;
+        if (slot == 63 || t + 1 == T_it) {
+            const int nrows = slot + 1;
+            const double sig = sqrt(sp_cap / g_cap);
+            if (lane < nrows) rows[lane * K1 + K] = sig;
+            double* dst = uout + (t - slot) * K1;
+            for (int idx = lane; idx < nrows * K1; idx += 64) dst[idx] = rows[idx];
+        }
     }
-    if (lane == 0 && T_it > 0) uout[(T_it - 1) * (K + 1) + K] = sqrt(sp_eff / g_eff);
 }
 
 // ======================================================================================
