@@ -168,7 +168,14 @@ void gibbs_loop_kernel(GibbsArgs a) {
     const double* xi = a.xi + (int64_t)chain * T_it * K;
     const double* gam = a.gam + (int64_t)chain * T_it;
     double* uout = a.uout + (int64_t)chain * T_it * (K + 1);
+    // the wave that records the draws (group 0): wave 1 -- on a SIMD of its own -- rather than the
+    // last one, which at five waves on four SIMDs shares the leader's SIMD and would issue its
+    // ~35 f64 operations of sqrt(sp / g) per iteration beside the serial chain
+#ifdef BMC_REC_LAST
     const bool recorder = (g == 0) && (wave == nw - 1);
+#else
+    const bool recorder = (g == 0) && (wave == (nw > 1 ? 1 : 0));
+#endif
 
     // Every load issued so far (the panels into registers) is complete from here on, and hipcc
     // knows it: otherwise it guards the first FMA of every iteration with s_waitcnt vmcnt(0),
