@@ -3,7 +3,8 @@
 that one rocprofv3 pass set (scripts/profile_round.sh) sees them: several chains per pass
 (gibbs_multi_kernel) at C4 / C5 / 410 MB, the streaming loop, the residual and Gram kernels at
 C4 / C5, the posterior predictive at C5 (M = 50000, 257 models, 10000 draws) and the simplex
-sampler at the C2 size.  Measurement workload only; prints one line per case."""
+sampler at the C2 size, and the one-wave kernels at the reference's own size (C1: N = 629,
+3 components).  Measurement workload only; prints one line per case."""
 import os
 import sys
 
@@ -40,6 +41,16 @@ def main():
     _, acc, used, st = ctx.simplex_run(Vt_hat, p["S_hat"], 4000, 1.0, 0.02, 1000, 0.001, seed=3,
                                        return_stats=True)
     print(f"simplex c2: {st['loop_ms'] * 1e3 / 5000:.3f} us/iter, accepted {acc}", flush=True)
+    # C1, the reference's own size: one wave per chain (gibbs_wave_kernel / simplex_wave_kernel)
+    p1 = synth_problem(629, 4, 3, seed=0)
+    ctx.set_problem(p1["y"], p1["X"])
+    ctx.set_prior(*p1["prior"])
+    for c in (1, 256):
+        _, st = ctx.gibbs_run(c, 20000, seeds=np.arange(c) + 1)
+        print(f"c1 x{c}: {st['loop_ms'] * 1e3 / 20000:.3f} us/iter (waves {st['waves_per_group']})", flush=True)
+    _, acc, used, st = ctx.simplex_run(p1["Vt"] / p1["S_hat"][:, None], p1["S_hat"], 20000, 1.0, 0.02, 1000,
+                                       0.001, seed=3, return_stats=True)
+    print(f"simplex c1: {st['loop_ms'] * 1e3 / 21000:.3f} us/step, accepted {acc}", flush=True)
     for tag, n, k, dt, it1, it8 in (("c4", 200000, 64, np.float32, 2000, 500),
                                     ("c5", 50000, 256, np.float64, 1000, 300),
                                     ("hbm", 400000, 256, np.float32, 200, 60)):
