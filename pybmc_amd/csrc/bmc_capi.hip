@@ -363,7 +363,8 @@ Chip chip_of(const bmc_ctx* c) {
 
 // Pick the launch geometry.  Preference order: row panels in VGPRs with each chain on
 // one XCD (8 slots x <= 32 groups), then panels pinned in LDS, then streaming.
-Geometry choose_geometry(const bmc_ctx* c, int n_chains, bool allow_one_wave = false) {
+Geometry choose_geometry(const bmc_ctx* c, int n_chains, bool allow_one_wave = false,
+                         bool allow_many_waves = false) {
     const Chip chip = chip_of(c);
     const int MAX_GROUPS_PER_LAUNCH = chip.groups_max, XCD_COUNT = chip.xcds,
               CU_PER_XCD = chip.cu_per_xcd;
@@ -391,12 +392,19 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains, bool allow_one_wave = f
     // explicit panels_per_wave keep the workgroup form.
     if (allow_one_wave && (tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec == 1 &&
         tu.groups_per_chain <= 1 && tu.waves_per_group <= 1 && tu.panels_per_wave <= 0) {
-        const int fmas = bmc::gibbs_wave_capacity(c->k, (int)NP);
-        if (fmas > 0 && (fmas <= ONE_WAVE_MAX_FMAS || tu.waves_per_group == 1)) {
+        // 1, 2 or 4 waves (one per SIMD): the fewest that keep a wave's FMAs per iteration
+        // within the measured crossover; the simplex kernel exists for one wave only
+        int nw = 0, fmas = 0;
+        for (int w : {1, 2, 4}) {
+            if (w > 1 && (!allow_many_waves || tu.waves_per_group == 1)) break;
+            const int f = bmc::gibbs_wave_capacity(c->k, (int)((NP + w - 1) / w));
+            if (f > 0 && (f <= ONE_WAVE_MAX_FMAS || tu.waves_per_group == 1)) { nw = w; fmas = f; break; }
+        }
+        if (nw > 0 && fmas > 0) {
             g.mode = 0;
-            g.ppw = (int)NP;
+            g.ppw = (int)((NP + nw - 1) / nw);
             g.G = 1;
-            g.waves = 1;
+            g.waves = nw;
             g.ppg = (int)NP;
             g.chains_per_launch = n_chains < 2048 ? n_chains : 2048;
             g.nslot = g.chains_per_launch;
@@ -601,7 +609,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         d_samples = (double*)c->samples.p;
     }
     if ((rc = check_tuning_fits(c))) return rc;
-    Geometry geo = choose_geometry(c, n_chains, true);
+    Geometry geo = choose_geometry(c, n_chains, true, true);
     // One-XCD register residency with more than 8 chains.
     // (a) 16 chains or more: the register-resident panels of an XCD's 32 groups serve a BUNDLE of
     //     2 / 4 / 8 chains per pass (gibbs_multi_kernel, one bundle per XCD: 16 .. 64 chains in one

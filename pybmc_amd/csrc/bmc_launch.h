@@ -183,7 +183,8 @@ struct GramArgs {
 };
 hipError_t launch_gibbs_gram(const GramArgs& a, hipStream_t s);
 // register-resident FMAs per iteration of the one-wave-per-chain kernel for k columns and
-// npanels panels of 64 rows (f64 or f32 storage, one row per lane), 0 = no such kernel
+// npanels panels of 64 rows PER WAVE (f64 or f32 storage, one row per lane), 0 = no such kernel;
+// a chain runs in 1, 2 or 4 such waves (GibbsArgs.waves)
 int gibbs_wave_capacity(int k, int npanels);
 
 struct SimplexArgs {

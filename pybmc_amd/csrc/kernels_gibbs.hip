@@ -713,10 +713,18 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
 // chain acc = y, acc = fma(-x_j, u_j, acc), j ascending, rows summed into two accumulators.
 // ======================================================================================
 template <typename T, int RMAX, int KMAX>
-__global__ __launch_bounds__(64) void gibbs_wave_kernel(GibbsArgs a) {
+__global__ __launch_bounds__(256) void gibbs_wave_kernel(GibbsArgs a) {
     // 64 output rows [u_t, sigma_t] staged here and written out together (below)
     __shared__ double rows[64 * (KMAX + 1)];
-    const int lane = threadIdx.x, K = a.P.k, NP = a.P.npanels;
+    __shared__ double wsum[2][4];   // (2 or 4 waves per chain: the waves' totals, two parities)
+    const int lane = threadIdx.x & 63, K = a.P.k, NP = a.P.npanels;
+    // Up to 4 waves per chain (a.waves; one per SIMD, so each still has 512 registers): wave w
+    // keeps panels [w rpw, (w + 1) rpw) and EVERY wave runs the whole iteration -- the draw, the
+    // sigma2 step -- on identical inputs; what they exchange is one double per wave and
+    // iteration, through LDS, with one barrier.  N = 2500, K = 8: 4 x 12 x 8 registers.
+    const int nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rpw = (NP + nw - 1) / nw, p0 = wave * rpw;
     const int chain = blockIdx.x;
     if (chain >= a.n_chains) return;
     const int64_t T_it = a.iters;
@@ -728,16 +736,20 @@ __global__ __launch_bounds__(64) void gibbs_wave_kernel(GibbsArgs a) {
     double x[RMAX][KMAX], y[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
+        const bool have = r < rpw && p0 + r < NP;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
-            x[r][j] = (r < NP && j < K) ? (double)Xp[((size_t)r * K + j) * 64 + lane] : 0.0;
-        y[r] = r < NP ? (double)yp[(size_t)r * 64 + lane] : 0.0;
+            x[r][j] = (have && j < K) ? (double)Xp[((size_t)(p0 + r) * K + j) * 64 + lane] : 0.0;
+        y[r] = have ? (double)yp[(size_t)(p0 + r) * 64 + lane] : 0.0;
     }
     const bool act = lane < K;
     // (lanes K .. 63: lam = c1 = c2 = xi = 0 draw u = 0 -- no exec-mask region around the draw)
     const double lam = act ? a.lam[lane] : 0.0, c1 = act ? a.c1[lane] : 0.0;
     const double c2 = act ? a.c2[lane] : 0.0;
-    if (lane == 0) a.placement[chain] = 1;
+    if (threadIdx.x == 0) a.placement[chain] = 1;
+    const bool rec = wave == 0;          // the wave that records the draws
+    if (threadIdx.x < 8) wsum[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;   // absent waves stay 0
+    __syncthreads();
     double sp_eff = a.sigma2_init, g_eff = 1.0;
     double sp_cap = 1.0, g_cap = 1.0;   // lane i: the (sp, g) pair behind staged row i
     double xi_next = (act && T_it > 0) ? xi[lane] : 0.0;
@@ -756,7 +768,7 @@ __global__ __launch_bounds__(64) void gibbs_wave_kernel(GibbsArgs a) {
             xi_next = act ? xi[tn * K + lane] : 0.0;
             gam_next = gam[tn];
         }
-        if (act) rows[slot * K1 + lane] = u;
+        if (act && rec) rows[slot * K1 + lane] = u;
         double uj[KMAX];
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) uj[j] = readlane_f64(u, j);
@@ -769,7 +781,15 @@ __global__ __launch_bounds__(64) void gibbs_wave_kernel(GibbsArgs a) {
             if (r & 1) part1 = fma(acc, acc, part1);
             else part0 = fma(acc, acc, part0);
         }
-        const double rss = wave_sum(part0 + part1);
+        double rss = wave_sum(part0 + part1);
+        if (nw > 1) {
+            // the waves' totals, in wave order; parity t & 1: a wave that is already in iteration
+            // t + 1 writes the other set while a slower one still reads this one
+            double* ws = wsum[t & 1];
+            if (lane == 0) ws[wave] = rss;
+            __syncthreads();
+            rss = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        }
         // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
         const double scale_post = (a.nu0_s20 + rss) * 0.5;
         const bool floor_hit = scale_post < 1e-6 * gam_t;
@@ -784,7 +804,7 @@ __global__ __launch_bounds__(64) void gibbs_wave_kernel(GibbsArgs a) {
         const bool mine = lane == slot;
         sp_cap = mine ? sp_eff : sp_cap;
         g_cap = mine ? g_eff : g_cap;
-        if (slot == 63 || t + 1 == T_it) {
+        if (rec && (slot == 63 || t + 1 == T_it)) {
             const int nrows = slot + 1;
             const double sig = sqrt(sp_cap / g_cap);
             if (lane < nrows) rows[lane * K1 + K] = sig;
@@ -1326,7 +1346,7 @@ __global__ __launch_bounds__(64) void simplex_wave_kernel(SimplexArgs a) {
 // row panels x columns a wave keeps: RMAX * KMAX <= 128 (and at most 16 panels = 1024 rows)
 static constexpr int wave_kmax(int k) { return k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 0; }
 static constexpr int wave_rmax(int np) { return np <= 2 ? 2 : np <= 4 ? 4 : np <= 8 ? 8 : np <= 12 ? 12 : np <= 16 ? 16 : 0; }
-int gibbs_wave_capacity(int k, int npanels) {
+int gibbs_wave_capacity(int k, int npanels) {   // npanels: per WAVE
     const int km = wave_kmax(k), rm = wave_rmax(npanels);
     return (km > 0 && rm > 0 && km * rm <= 128) ? km * rm : 0;
 }
@@ -1338,7 +1358,7 @@ static const void* wave_kernel_of(SimplexTag) { return (const void*)simplex_wave
 
 template <typename Tag, typename T, int RMAX, typename Args>
 static hipError_t launch_wave_r(const Args& a, int n_blocks, hipStream_t s) {
-    const dim3 grid((unsigned)n_blocks), block(64);
+    const dim3 grid((unsigned)n_blocks), block(64 * (a.waves > 1 ? a.waves : 1));
 #define BMC_WV(KM)                                                                              \
     if constexpr (RMAX * KM <= 128)                                                             \
         return launch_or_query(wave_kernel_of<T, RMAX, KM>(Tag{}), grid, block, 0, s, a,        \
@@ -1356,9 +1376,13 @@ static hipError_t launch_wave_r(const Args& a, int n_blocks, hipStream_t s) {
 
 template <typename Tag, typename T, typename Args>
 static hipError_t launch_wave(const Args& a, int n_blocks, hipStream_t s) {
-    if (a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, a.P.npanels) || n_blocks < 1)
+    // (the simplex kernel runs in one wave; the Gibbs kernel in 1, 2 or 4, a.waves)
+    const int nw = a.waves > 1 ? a.waves : 1;
+    const int rpw = (a.P.npanels + nw - 1) / nw;
+    if (a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, rpw) || n_blocks < 1 || (nw != 1 && nw != 2 && nw != 4) ||
+        (nw > 1 && !std::is_same<Tag, GibbsTag>::value))
         return hipErrorInvalidValue;
-    switch (wave_rmax(a.P.npanels)) {
+    switch (wave_rmax(rpw)) {
         case 2: return launch_wave_r<Tag, T, 2>(a, n_blocks, s);
         case 4: return launch_wave_r<Tag, T, 4>(a, n_blocks, s);
         case 8: return launch_wave_r<Tag, T, 8>(a, n_blocks, s);

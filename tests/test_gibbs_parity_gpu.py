@@ -274,6 +274,47 @@ def test_one_wave_chains(n, k, dt):
         assert np.abs(out[0] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n,k,dt,nw", [(1024, 8, np.float64, 2), (2500, 8, np.float64, 4),
+                                       (4000, 4, np.float64, 4), (1500, 3, np.float32, 2),
+                                       (2100, 7, np.float32, 4)])
+def test_chains_in_two_or_four_waves(n, k, dt, nw):
+    """A few thousand rows and a few columns: the chain runs in 2 or 4 waves of ONE workgroup
+    (gibbs_wave_kernel), every wave with its share of the rows in registers and every wave
+    running the whole iteration; the waves exchange one double per iteration through LDS.
+    Equal to the workgroup form (gibbs_loop_kernel) to rounding, to the replayed oracle chain,
+    independent of the number of chains in the launch and of the iteration count."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(5 * n + k)
+    X = (rng.standard_normal((n, k)) / np.sqrt(n)).astype(dt)
+    y = (X.astype(np.float64) @ rng.standard_normal(k) + 0.1 * rng.standard_normal(n)).astype(dt)
+    prior = (np.zeros(k), np.eye(k) * 10.0, 1.0, 0.02)
+    ctx.set_problem(y, np.asfortranarray(X), dtype=dt)
+    ctx.set_prior(*prior)
+    seeds = np.arange(40) + 9
+    for T in (1, 64, 65, 200):
+        many, st = ctx.gibbs_run(40, T, seeds=seeds)
+        assert st["waves_per_group"] == nw and st["groups_per_chain"] == 1 and st["launches"] == 1, st
+        solo, _ = ctx.gibbs_run(1, T, seeds=seeds[17:18])
+        assert np.array_equal(many[17], solo[0]), T
+    ctx.set_tuning(waves_per_group=8)
+    group, stg = ctx.gibbs_run(2, 200, seeds=seeds[[0, 39]])
+    ctx.set_tuning()
+    assert stg["waves_per_group"] == 8
+    scale = max(1.0, np.abs(group).max())
+    assert np.abs(many[0] - group[0]).max() < 1e-11 * scale
+    assert np.abs(many[39] - group[1]).max() < 1e-11 * scale
+    if dt == np.float64:
+        st_o = O.chain_setup(y, X, prior)
+        Z, G = O.reference_streams(21, 22, 70, k, O.gamma_shape(st_o))
+        ref, trace = O.gibbs_replay(y, X, 70, prior, Z, G, return_sigma2=True)
+        W, lam, _ = ctx.basis()
+        xi = O.innovations_in_basis(st_o, y, X, ref, W, lam, trace)
+        out, st = ctx.gibbs_run(2, 70, xi=np.repeat(xi[None], 2, 0), g=np.repeat(G[None], 2, 0))
+        assert st["waves_per_group"] == nw
+        assert np.array_equal(out[0], out[1])
+        assert np.abs(out[0] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
 # ---------------------------------------------------------------- edge cases
 def test_edge_shapes():
     ctx = gpu_ctx()
