@@ -51,6 +51,13 @@ def main():
     _, acc, used, st = ctx.simplex_run(p1["Vt"] / p1["S_hat"][:, None], p1["S_hat"], 20000, 1.0, 0.02, 1000,
                                        0.001, seed=3, return_stats=True)
     print(f"simplex c1: {st['loop_ms'] * 1e3 / 21000:.3f} us/step, accepted {acc}", flush=True)
+    # a few thousand rows: the same kernel in 4 waves per chain
+    yq, Xq, priorq = dense(2500, 8, np.float64)
+    ctx.set_problem(yq, Xq)
+    ctx.set_prior(*priorq)
+    for c in (1, 256):
+        _, st = ctx.gibbs_run(c, 10000, seeds=np.arange(c) + 1)
+        print(f"n2500k8 x{c}: {st['loop_ms'] * 1e3 / 10000:.3f} us/iter (waves {st['waves_per_group']})", flush=True)
     for tag, n, k, dt, it1, it8 in (("c4", 200000, 64, np.float32, 2000, 500),
                                     ("c5", 50000, 256, np.float64, 1000, 300),
                                     ("hbm", 400000, 256, np.float32, 200, 60)):
