@@ -712,8 +712,8 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
 // The draw and the sigma2 step are those of gibbs_loop_kernel; per row the residual is the
 // chain acc = y, acc = fma(-x_j, u_j, acc), j ascending, rows summed into two accumulators.
 // ======================================================================================
-template <typename T, int RMAX, int KMAX>
-__global__ __launch_bounds__(256) void gibbs_wave_kernel(GibbsArgs a) {
+template <typename T, int RMAX, int KMAX, bool MANY = false>
+__global__ __launch_bounds__(MANY ? 256 : 64) void gibbs_wave_kernel(GibbsArgs a) {
     // 64 output rows [u_t, sigma_t] staged here and written out together (below)
     __shared__ double rows[64 * (KMAX + 1)];
     __shared__ double wsum[2][4];   // (2 or 4 waves per chain: the waves' totals, two parities)
@@ -722,8 +722,10 @@ __global__ __launch_bounds__(256) void gibbs_wave_kernel(GibbsArgs a) {
     // keeps panels [w rpw, (w + 1) rpw) and EVERY wave runs the whole iteration -- the draw, the
     // sigma2 step -- on identical inputs; what they exchange is one double per wave and
     // iteration, through LDS, with one barrier.  N = 2500, K = 8: 4 x 12 x 8 registers.
-    const int nw = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (MANY is a template parameter: with the test at run time the one-wave chain of the
+    // reference's size went from 0.351 to 0.381 us per iteration)
+    const int nw = MANY ? (int)(blockDim.x >> 6) : 1;
+    const int wave = MANY ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int rpw = (NP + nw - 1) / nw, p0 = wave * rpw;
     const int chain = blockIdx.x;
     if (chain >= a.n_chains) return;
@@ -748,8 +750,10 @@ __global__ __launch_bounds__(256) void gibbs_wave_kernel(GibbsArgs a) {
     const double c2 = act ? a.c2[lane] : 0.0;
     if (threadIdx.x == 0) a.placement[chain] = 1;
     const bool rec = wave == 0;          // the wave that records the draws
-    if (threadIdx.x < 8) wsum[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;   // absent waves stay 0
-    __syncthreads();
+    if constexpr (MANY) {
+        if (threadIdx.x < 8) wsum[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;   // absent waves stay 0
+        __syncthreads();
+    }
     double sp_eff = a.sigma2_init, g_eff = 1.0;
     double sp_cap = 1.0, g_cap = 1.0;   // lane i: the (sp, g) pair behind staged row i
     double xi_next = (act && T_it > 0) ? xi[lane] : 0.0;
@@ -782,7 +786,7 @@ __global__ __launch_bounds__(256) void gibbs_wave_kernel(GibbsArgs a) {
             else part0 = fma(acc, acc, part0);
         }
         double rss = wave_sum(part0 + part1);
-        if (nw > 1) {
+        if constexpr (MANY) {
             // the waves' totals, in wave order; parity t & 1: a wave that is already in iteration
             // t + 1 writes the other set while a slower one still reads this one
             double* ws = wsum[t & 1];
@@ -1352,16 +1356,18 @@ int gibbs_wave_capacity(int k, int npanels) {   // npanels: per WAVE
 }
 
 template <typename T, int RMAX, int KM>
-static const void* wave_kernel_of(GibbsTag) { return (const void*)gibbs_wave_kernel<T, RMAX, KM>; }
+static const void* wave_kernel_of(GibbsTag, bool many) {
+    return many ? (const void*)gibbs_wave_kernel<T, RMAX, KM, true> : (const void*)gibbs_wave_kernel<T, RMAX, KM, false>;
+}
 template <typename T, int RMAX, int KM>
-static const void* wave_kernel_of(SimplexTag) { return (const void*)simplex_wave_kernel<T, RMAX, KM>; }
+static const void* wave_kernel_of(SimplexTag, bool) { return (const void*)simplex_wave_kernel<T, RMAX, KM>; }
 
 template <typename Tag, typename T, int RMAX, typename Args>
 static hipError_t launch_wave_r(const Args& a, int n_blocks, hipStream_t s) {
     const dim3 grid((unsigned)n_blocks), block(64 * (a.waves > 1 ? a.waves : 1));
 #define BMC_WV(KM)                                                                              \
     if constexpr (RMAX * KM <= 128)                                                             \
-        return launch_or_query(wave_kernel_of<T, RMAX, KM>(Tag{}), grid, block, 0, s, a,        \
+        return launch_or_query(wave_kernel_of<T, RMAX, KM>(Tag{}, a.waves > 1), grid, block, 0, s, a, \
                                a.query_occupancy);                                              \
     break
     switch (wave_kmax(a.P.k)) {
