@@ -571,6 +571,9 @@ __global__ __launch_bounds__(512) void gibbs_multi_kernel(GibbsArgs a) {
         // group 0's leaders record their chain (row t, and sigma of the previous row) between
         // publishing and polling: the stamps showed this work, placed after the exchange, holding
         // back group 0 -- and with it every group -- by ~1500 cycles per pass
+        // (round 3, tried: the sqrt(sp / g) deferred to 64 roots at a time, as in gibbs_wave_kernel --
+        // slower here, 64 chains at C2 2.110 -> 2.146 us, N = 100 000 x 8 chains 5.90 -> 6.04: this
+        // slot is already hidden behind the exchange, and the captures add to every iteration)
         auto record = [&]() {
             if (g == 0) {
 #pragma unroll
