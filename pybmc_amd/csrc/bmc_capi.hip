@@ -393,7 +393,7 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains, bool allow_one_wave = f
     if (allow_one_wave && (tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec == 1 &&
         tu.groups_per_chain <= 1 && tu.waves_per_group <= 1 && tu.panels_per_wave <= 0) {
         // 1, 2 or 4 waves (one per SIMD): the fewest that keep a wave's FMAs per iteration
-        // within the measured crossover; the simplex kernel exists for one wave only
+        // within the measured crossover
         int nw = 0, fmas = 0;
         for (int w : {1, 2, 4}) {
             if (w > 1 && (!allow_many_waves || tu.waves_per_group == 1)) break;
@@ -1403,7 +1403,7 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     std::vector<double> step(K);
     for (int j = 0; j < K; ++j) step[j] = std::sqrt(S_hat[j] * S_hat[j] * stepsize * stepsize);  // :80
     if ((rc = check_tuning_fits(c))) return rc;
-    const Geometry geo = choose_geometry(c, 1, Km <= 64);   // (one wave: a model per lane)
+    const Geometry geo = choose_geometry(c, 1, Km <= 64, Km <= 64);   // (a model per lane)
     const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)3 * gran_stride * 8))) return rc;
     HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)3 * gran_stride * 8, c->stream));

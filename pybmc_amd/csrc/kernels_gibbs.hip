@@ -1252,10 +1252,16 @@ static hipError_t launch_multi_reg(const GibbsArgs& a, hipStream_t s) {
 // proposal, the simplex test of its weights, the residual sum of an inside proposal, the
 // Metropolis test, the sigma2 draw), at most 64 models: lane m keeps column m of Vt_hat.  The
 // kept rows [beta_t, sigma_t] are staged 64 at a time as in gibbs_wave_kernel.
-template <typename T, int RMAX, int KMAX>
-__global__ __launch_bounds__(64) void simplex_wave_kernel(SimplexArgs a) {
+template <typename T, int RMAX, int KMAX, bool MANY = false>
+__global__ __launch_bounds__(MANY ? 256 : 64) void simplex_wave_kernel(SimplexArgs a) {
     __shared__ double rows[64 * (KMAX + 1)];
-    const int lane = threadIdx.x, K = a.P.k, NP = a.P.npanels, Km = a.Km;
+    __shared__ double wsum[2][4];   // (MANY: 2 or 4 waves, as in gibbs_wave_kernel)
+    const int lane = threadIdx.x & 63, K = a.P.k, NP = a.P.npanels, Km = a.Km;
+    const int nw = MANY ? (int)(blockDim.x >> 6) : 1;
+    const int wave = MANY ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    const int rpw = (NP + nw - 1) / nw, p0 = wave * rpw;
+    const bool rec = wave == 0;
+    unsigned nex = 0;   // residual sums exchanged so far (parity of the LDS slots)
     if (blockIdx.x != 0) return;
     const int64_t T_tot = a.burn + a.iters;
     const T* Xp = reinterpret_cast<const T*>(a.P.X);
@@ -1263,16 +1269,21 @@ __global__ __launch_bounds__(64) void simplex_wave_kernel(SimplexArgs a) {
     double x[RMAX][KMAX], y[RMAX], vtr[KMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
+        const bool have = r < rpw && p0 + r < NP;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
-            x[r][j] = (r < NP && j < K) ? (double)Xp[((size_t)r * K + j) * 64 + lane] : 0.0;
-        y[r] = r < NP ? (double)yp[(size_t)r * 64 + lane] : 0.0;
+            x[r][j] = (have && j < K) ? (double)Xp[((size_t)(p0 + r) * K + j) * 64 + lane] : 0.0;
+        y[r] = have ? (double)yp[(size_t)(p0 + r) * 64 + lane] : 0.0;
+    }
+    if constexpr (MANY) {
+        if (threadIdx.x < 8) wsum[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;
+        __syncthreads();
     }
     const bool act = lane < K, model = lane < Km;
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) vtr[j] = (j < K && model) ? a.Vt[(size_t)j * Km + lane] : 0.0;
     const double step = act ? a.step[lane] : 0.0;
-    if (lane == 0) a.placement[0] = 1;
+    if (threadIdx.x == 0) a.placement[0] = 1;
     double b_cur = 0.0;                                 // :82
     double rss_cur = a.rss_init;                        // -log_likelihood_current (:85)
     double s2 = a.rss_init / (double)a.P.n;             // :86
@@ -1311,9 +1322,16 @@ __global__ __launch_bounds__(64) void simplex_wave_kernel(SimplexArgs a) {
                 if (r & 1) part1 = fma(acc, acc, part1);
                 else part0 = fma(acc, acc, part0);
             }
-            const double rss_prop = wave_sum(part0 + part1);
+            double rss_prop = wave_sum(part0 + part1);
+            if constexpr (MANY) {   // every wave takes this branch together: identical tests
+                double* ws = wsum[nex & 1];
+                if (lane == 0) ws[wave] = rss_prop;
+                __syncthreads();
+                rss_prop = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+                ++nex;
+            }
             if (iu >= a.n_unif) {
-                if (lane == 0) a.status[0] = 2;
+                if (threadIdx.x == 0) a.status[0] = 2;
                 break;
             }
             // min(1, exp((ll_prop - ll_cur) / sigma2)), ll = -rss     (:106-109)
@@ -1333,9 +1351,9 @@ __global__ __launch_bounds__(64) void simplex_wave_kernel(SimplexArgs a) {
         if (t >= a.burn) {
             const int64_t kept = t - a.burn;
             const int slot = (int)(kept & 63);
-            if (act) rows[slot * K1 + lane] = b_cur;
+            if (act && rec) rows[slot * K1 + lane] = b_cur;
             s2_cap = lane == slot ? s2 : s2_cap;
-            if (slot == 63 || t + 1 == T_tot) {
+            if (rec && (slot == 63 || t + 1 == T_tot)) {
                 const int nrows = slot + 1;
                 const double sig = sqrt(s2_cap);
                 if (lane < nrows) rows[lane * K1 + K] = sig;
@@ -1344,7 +1362,7 @@ __global__ __launch_bounds__(64) void simplex_wave_kernel(SimplexArgs a) {
             }
         }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         a.counters[0] = accepted;
         a.counters[1] = iu;
     }
@@ -1363,7 +1381,10 @@ static const void* wave_kernel_of(GibbsTag, bool many) {
     return many ? (const void*)gibbs_wave_kernel<T, RMAX, KM, true> : (const void*)gibbs_wave_kernel<T, RMAX, KM, false>;
 }
 template <typename T, int RMAX, int KM>
-static const void* wave_kernel_of(SimplexTag, bool) { return (const void*)simplex_wave_kernel<T, RMAX, KM>; }
+static const void* wave_kernel_of(SimplexTag, bool many) {
+    return many ? (const void*)simplex_wave_kernel<T, RMAX, KM, true>
+                : (const void*)simplex_wave_kernel<T, RMAX, KM, false>;
+}
 
 template <typename Tag, typename T, int RMAX, typename Args>
 static hipError_t launch_wave_r(const Args& a, int n_blocks, hipStream_t s) {
@@ -1385,11 +1406,9 @@ static hipError_t launch_wave_r(const Args& a, int n_blocks, hipStream_t s) {
 
 template <typename Tag, typename T, typename Args>
 static hipError_t launch_wave(const Args& a, int n_blocks, hipStream_t s) {
-    // (the simplex kernel runs in one wave; the Gibbs kernel in 1, 2 or 4, a.waves)
     const int nw = a.waves > 1 ? a.waves : 1;
     const int rpw = (a.P.npanels + nw - 1) / nw;
-    if (a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, rpw) || n_blocks < 1 || (nw != 1 && nw != 2 && nw != 4) ||
-        (nw > 1 && !std::is_same<Tag, GibbsTag>::value))
+    if (a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, rpw) || n_blocks < 1 || (nw != 1 && nw != 2 && nw != 4))
         return hipErrorInvalidValue;
     switch (wave_rmax(rpw)) {
         case 2: return launch_wave_r<Tag, T, 2>(a, n_blocks, s);

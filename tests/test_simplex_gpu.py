@@ -74,6 +74,35 @@ def test_replay_is_geometry_independent():
     ctx.set_tuning(0, 0)
 
 
+@pytest.mark.parametrize("n,k,km,nw", [(2500, 3, 4, 4), (1024, 8, 9, 2), (4000, 4, 6, 4)])
+def test_chain_in_two_or_four_waves_matches_the_workgroup_form(n, k, km, nw):
+    """A few thousand rows: the simplex sampler runs in 2 or 4 register-resident waves of one
+    workgroup (simplex_wave_kernel, every wave running the whole step).  Same variates, same
+    decisions, same chain as the workgroup form (simplex_loop_kernel)."""
+    ctx = gpu_ctx()
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((n, km))
+    truth = A @ np.full(km, 1.0 / km) + 0.05 * rng.standard_normal(n)
+    Ac = A - A.mean(1, keepdims=True)
+    U, S, Vt = np.linalg.svd(Ac, full_matrices=False)
+    X = U[:, :k]
+    S_hat = S[:k]
+    Vt_hat = Vt[:k] / S_hat[:, None]
+    y = truth - A.mean(1)
+    ctx.set_problem(y, X)
+    burn, T = 300, 1000
+    out, acc, used, st = ctx.simplex_run(Vt_hat, S_hat, T, 1.0, 0.02, burn, 0.001, seed=5, return_stats=True)
+    assert st["waves_per_group"] == nw and st["groups_per_chain"] == 1, st
+    ctx.set_tuning(waves_per_group=8)
+    ref, acc2, used2, st2 = ctx.simplex_run(Vt_hat, S_hat, T, 1.0, 0.02, burn, 0.001, seed=5, return_stats=True)
+    ctx.set_tuning()
+    assert st2["waves_per_group"] == 8
+    assert acc == acc2 and used == used2 and 0 < acc
+    assert np.abs(out - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    w = out[:, :k] @ Vt_hat + 1.0 / km
+    assert (w >= 0).all()
+
+
 def test_reference_surface():  # reference tests/test_inference_utils.py:21-32, 47-76
     y = np.array([1.0, 2.0, 3.0])
     X = np.array([[1, 0], [0, 1], [1, 1]])
