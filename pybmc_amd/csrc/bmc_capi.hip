@@ -134,11 +134,12 @@ void release(DevBuf& b) {
 // matter here (13.2 MB of samples at C2: 29 ms, against 0.3 ms of DMA -- bench.py extra.e2e).
 // Instead: DMA into two pinned staging blocks in turn and copy out of one with the CPU while the
 // next is in flight; large results are copied out by several host threads (one thread moves
-// ~8 GB/s into untouched pages, the 4 GB of C5's rndm_m would take 0.5 s).
+// ~8 GB/s into untouched pages, the 4 GB of C5's rndm_m would take 0.5 s): 8 threads from 8 MB on.
 constexpr size_t HSTAGE_BYTES = (size_t)32 << 20;
 void host_copy(char* dst, const char* src, size_t bytes) {
     const size_t MT_MIN = (size_t)8 << 20;
-    unsigned nt = bytes >= MT_MIN ? 4 : 1;
+    // (C5's 4 GB of draws, whole bmc_predict call: 2 threads 0.184 s, 4 0.119, 8 0.097, 16 0.093)
+    unsigned nt = bytes >= MT_MIN ? 8 : 1;
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && nt > hw) nt = hw;
     if (nt <= 1) {
