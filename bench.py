@@ -636,6 +636,33 @@ def extras(ctx, torch, dev, local_rank, N, K, T):
     finally:
         ctx.set_tuning()
     try:
+        # the reference's own sizes (BASELINE configs[0]: 629 rows; a few thousand rows): one wave,
+        # or 2 / 4 waves of one workgroup, per chain (gibbs_wave_kernel) -- the loop alone
+        small = {}
+        for tag, n_s, k_s in (("c1_n629_k3", 629, 3), ("n2500_k8", 2500, 8)):
+            rng_s = np.random.Generator(np.random.PCG64(n_s))
+            Xs = rng_s.standard_normal((n_s, k_s)) / np.sqrt(n_s)
+            ys = Xs @ rng_s.standard_normal(k_s) + 0.1 * rng_s.standard_normal(n_s)
+            ctx.set_problem(ys, np.asfortranarray(Xs))
+            ctx.set_prior(np.zeros(k_s), np.eye(k_s) * 10.0, 1.0, 0.02)
+            row = {}
+            for cs in (1, 256):
+                Ts = 50000 if cs == 1 else 5000
+                outs = torch.empty((cs, Ts, k_s + 1), dtype=torch.float64, device=dev)
+                ss = chain_seeds(1, list(range(cs)))
+                ctx.gibbs_run_device(cs, Ts, ss, outs.data_ptr())
+                sts = ctx.gibbs_run_device(cs, Ts, ss, outs.data_ptr())
+                row[f"chains{cs}"] = {"us_per_iteration_all": sts["loop_ms"] * 1e3 / Ts,
+                                      "samples_per_s": cs * Ts / (sts["loop_ms"] * 1e-3),
+                                      "waves_per_chain": sts["waves_per_group"],
+                                      "groups_per_chain": sts["groups_per_chain"]}
+                del outs
+            small[tag] = row
+        small["reference_cpu"] = "train() 8 117 samples/s at N=629 (BASELINE.md section 2)"
+        extra["reference_sized_problems"] = small
+    except Exception as e:
+        extra["reference_sized_problems"] = {"error": str(e)}
+    try:
         # residual-reduction kernel at the C4 size (N=200000, K=64, f32 storage)
         rng = np.random.Generator(np.random.PCG64(4))
         X4 = np.asfortranarray(rng.standard_normal((200000, 64), dtype=np.float32))
