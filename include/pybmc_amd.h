@@ -49,7 +49,7 @@ typedef struct {
     int32_t waves_per_group;  /* 1..8 (workgroup = 64 * waves threads); 1 with no other knob set
                                  also asks for the one-wave-per-chain kernel wherever it exists
                                  (<= 1024 rows, rows/64 x columns <= 128; left to itself the
-                                 library also runs such chains in 2 or 4 waves, up to ~4000
+                                 library also runs such chains in 2, 4 or 8 waves, up to ~8000
                                  rows), > 1 keeps a small chain in the workgroup form */
     int32_t residency;        /* 0 auto, 1 registers, 2 LDS, 3 stream from HBM */
     int32_t panels_per_wave;  /* register residency: 1, 2 or 4 (1, asked for explicitly, also keeps

@@ -365,7 +365,7 @@ Chip chip_of(const bmc_ctx* c) {
 // Pick the launch geometry.  Preference order: row panels in VGPRs with each chain on
 // one XCD (8 slots x <= 32 groups), then panels pinned in LDS, then streaming.
 Geometry choose_geometry(const bmc_ctx* c, int n_chains, bool allow_one_wave = false,
-                         bool allow_many_waves = false) {
+                         int max_waves = 1) {
     const Chip chip = chip_of(c);
     const int MAX_GROUPS_PER_LAUNCH = chip.groups_max, XCD_COUNT = chip.xcds,
               CU_PER_XCD = chip.cu_per_xcd;
@@ -393,12 +393,13 @@ Geometry choose_geometry(const bmc_ctx* c, int n_chains, bool allow_one_wave = f
     // explicit panels_per_wave keep the workgroup form.
     if (allow_one_wave && (tu.residency == RES_AUTO || tu.residency == RES_REG) && c->vec == 1 &&
         tu.groups_per_chain <= 1 && tu.waves_per_group <= 1 && tu.panels_per_wave <= 0) {
-        // 1, 2 or 4 waves (one per SIMD): the fewest that keep a wave's FMAs per iteration
+        // 1, 2, 4 (one per SIMD) or 8 waves: the fewest that keep a wave's FMAs per iteration
         // within the measured crossover
         int nw = 0, fmas = 0;
-        for (int w : {1, 2, 4}) {
-            if (w > 1 && (!allow_many_waves || tu.waves_per_group == 1)) break;
+        for (int w : {1, 2, 4, 8}) {
+            if (w > 1 && (w > max_waves || tu.waves_per_group == 1)) break;
             const int f = bmc::gibbs_wave_capacity(c->k, (int)((NP + w - 1) / w));
+            if (w == 8 && f > 64) break;   // (8 waves: 256 registers each, shapes up to 64 FMAs)
             if (f > 0 && (f <= ONE_WAVE_MAX_FMAS || tu.waves_per_group == 1)) { nw = w; fmas = f; break; }
         }
         if (nw > 0 && fmas > 0) {
@@ -610,7 +611,7 @@ int run_common(bmc_ctx* c, int32_t n_chains, int64_t iters, const uint64_t* seed
         d_samples = (double*)c->samples.p;
     }
     if ((rc = check_tuning_fits(c))) return rc;
-    Geometry geo = choose_geometry(c, n_chains, true, true);
+    Geometry geo = choose_geometry(c, n_chains, true, 8);
     // One-XCD register residency with more than 8 chains.
     // (a) 16 chains or more: the register-resident panels of an XCD's 32 groups serve a BUNDLE of
     //     2 / 4 / 8 chains per pass (gibbs_multi_kernel, one bundle per XCD: 16 .. 64 chains in one
@@ -1404,7 +1405,7 @@ int bmc_simplex_run(bmc_ctx* c, const double* Vt_hat, int32_t Km, const double* 
     std::vector<double> step(K);
     for (int j = 0; j < K; ++j) step[j] = std::sqrt(S_hat[j] * S_hat[j] * stepsize * stepsize);  // :80
     if ((rc = check_tuning_fits(c))) return rc;
-    const Geometry geo = choose_geometry(c, 1, Km <= 64, Km <= 64);   // (a model per lane)
+    const Geometry geo = choose_geometry(c, 1, Km <= 64, 4);   // (a model per lane)
     const int gran_stride = bmc::gran_slot_words(geo.G);
     if ((rc = ensure(c, c->gran, (size_t)3 * gran_stride * 8))) return rc;
     HIPCHK(c, hipMemsetAsync(c->gran.p, 0, (size_t)3 * gran_stride * 8, c->stream));

@@ -715,11 +715,12 @@ __global__ __launch_bounds__(64) void gibbs_gram_kernel(GramArgs a) {
 // The draw and the sigma2 step are those of gibbs_loop_kernel; per row the residual is the
 // chain acc = y, acc = fma(-x_j, u_j, acc), j ascending, rows summed into two accumulators.
 // ======================================================================================
-template <typename T, int RMAX, int KMAX, bool MANY = false>
-__global__ __launch_bounds__(MANY ? 256 : 64) void gibbs_wave_kernel(GibbsArgs a) {
+template <typename T, int RMAX, int KMAX, int NWMAX = 1>
+__global__ __launch_bounds__(64 * NWMAX) void gibbs_wave_kernel(GibbsArgs a) {
+    constexpr bool MANY = NWMAX > 1;   // 4: 2 or 4 waves (512 registers each); 8: 8 waves (256 each)
     // 64 output rows [u_t, sigma_t] staged here and written out together (below)
     __shared__ double rows[64 * (KMAX + 1)];
-    __shared__ double wsum[2][4];   // (2 or 4 waves per chain: the waves' totals, two parities)
+    __shared__ double wsum[2][8];   // (2 .. 8 waves per chain: the waves' totals, two parities)
     const int lane = threadIdx.x & 63, K = a.P.k, NP = a.P.npanels;
     // Up to 4 waves per chain (a.waves; one per SIMD, so each still has 512 registers): wave w
     // keeps panels [w rpw, (w + 1) rpw) and EVERY wave runs the whole iteration -- the draw, the
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(MANY ? 256 : 64) void gibbs_wave_kernel(GibbsArgs a
     if (threadIdx.x == 0) a.placement[chain] = 1;
     const bool rec = wave == 0;          // the wave that records the draws
     if constexpr (MANY) {
-        if (threadIdx.x < 8) wsum[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;   // absent waves stay 0
+        if (threadIdx.x < 16) wsum[threadIdx.x >> 3][threadIdx.x & 7] = 0.0;   // absent waves stay 0
         __syncthreads();
     }
     double sp_eff = a.sigma2_init, g_eff = 1.0;
@@ -796,6 +797,7 @@ __global__ __launch_bounds__(MANY ? 256 : 64) void gibbs_wave_kernel(GibbsArgs a
             if (lane == 0) ws[wave] = rss;
             __syncthreads();
             rss = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+            if constexpr (NWMAX > 4) rss += (ws[4] + ws[5]) + (ws[6] + ws[7]);
         }
         // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
         const double scale_post = (a.nu0_s20 + rss) * 0.5;
@@ -1377,22 +1379,29 @@ int gibbs_wave_capacity(int k, int npanels) {   // npanels: per WAVE
 }
 
 template <typename T, int RMAX, int KM>
-static const void* wave_kernel_of(GibbsTag, bool many) {
-    return many ? (const void*)gibbs_wave_kernel<T, RMAX, KM, true> : (const void*)gibbs_wave_kernel<T, RMAX, KM, false>;
+static const void* wave_kernel_of(GibbsTag, int waves) {
+    if (waves > 4) {   // 8 waves: two per SIMD, 256 registers each -- the shapes that fit them
+        if constexpr (RMAX * KM <= 64) return (const void*)gibbs_wave_kernel<T, RMAX, KM, 8>;   // (12 x 8 spills at 256)
+        return nullptr;
+    }
+    return waves > 1 ? (const void*)gibbs_wave_kernel<T, RMAX, KM, 4> : (const void*)gibbs_wave_kernel<T, RMAX, KM, 1>;
 }
 template <typename T, int RMAX, int KM>
-static const void* wave_kernel_of(SimplexTag, bool many) {
-    return many ? (const void*)simplex_wave_kernel<T, RMAX, KM, true>
-                : (const void*)simplex_wave_kernel<T, RMAX, KM, false>;
+static const void* wave_kernel_of(SimplexTag, int waves) {
+    if (waves > 4) return nullptr;
+    return waves > 1 ? (const void*)simplex_wave_kernel<T, RMAX, KM, true>
+                     : (const void*)simplex_wave_kernel<T, RMAX, KM, false>;
 }
 
 template <typename Tag, typename T, int RMAX, typename Args>
 static hipError_t launch_wave_r(const Args& a, int n_blocks, hipStream_t s) {
     const dim3 grid((unsigned)n_blocks), block(64 * (a.waves > 1 ? a.waves : 1));
 #define BMC_WV(KM)                                                                              \
-    if constexpr (RMAX * KM <= 128)                                                             \
-        return launch_or_query(wave_kernel_of<T, RMAX, KM>(Tag{}, a.waves > 1), grid, block, 0, s, a, \
-                               a.query_occupancy);                                              \
+    if constexpr (RMAX * KM <= 128) {                                                           \
+        const void* fn = wave_kernel_of<T, RMAX, KM>(Tag{}, a.waves);                           \
+        if (!fn) return hipErrorInvalidValue;                                                   \
+        return launch_or_query(fn, grid, block, 0, s, a, a.query_occupancy);                    \
+    }                                                                                           \
     break
     switch (wave_kmax(a.P.k)) {
         case 4: BMC_WV(4);
@@ -1408,7 +1417,8 @@ template <typename Tag, typename T, typename Args>
 static hipError_t launch_wave(const Args& a, int n_blocks, hipStream_t s) {
     const int nw = a.waves > 1 ? a.waves : 1;
     const int rpw = (a.P.npanels + nw - 1) / nw;
-    if (a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, rpw) || n_blocks < 1 || (nw != 1 && nw != 2 && nw != 4))
+    if (a.P.vec != 1 || !gibbs_wave_capacity(a.P.k, rpw) || n_blocks < 1 ||
+        (nw != 1 && nw != 2 && nw != 4 && nw != 8))
         return hipErrorInvalidValue;
     switch (wave_rmax(rpw)) {
         case 2: return launch_wave_r<Tag, T, 2>(a, n_blocks, s);

@@ -276,9 +276,10 @@ def test_one_wave_chains(n, k, dt):
 
 @pytest.mark.parametrize("n,k,dt,nw", [(1024, 8, np.float64, 2), (2500, 8, np.float64, 4),
                                        (4000, 4, np.float64, 4), (1500, 3, np.float32, 2),
-                                       (2100, 7, np.float32, 4)])
+                                       (2100, 7, np.float32, 4), (8000, 4, np.float64, 8),
+                                       (6000, 3, np.float32, 8), (4096, 8, np.float64, 8)])
 def test_chains_in_two_or_four_waves(n, k, dt, nw):
-    """A few thousand rows and a few columns: the chain runs in 2 or 4 waves of ONE workgroup
+    """A few thousand rows and a few columns: the chain runs in 2, 4 or 8 waves of ONE workgroup
     (gibbs_wave_kernel), every wave with its share of the rows in registers and every wave
     running the whole iteration; the waves exchange one double per iteration through LDS.
     Equal to the workgroup form (gibbs_loop_kernel) to rounding, to the replayed oracle chain,
