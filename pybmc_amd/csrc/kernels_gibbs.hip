@@ -780,21 +780,19 @@ __global__ __launch_bounds__(64 * NWMAX) void gibbs_wave_kernel(GibbsArgs a) {
         double uj[KMAX];
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) uj[j] = readlane_f64(u, j);
-        // columns outside, rows inside: RMAX independent chains in flight (written row by row,
-        // hipcc reused one accumulator and ran the rows' K dependent FMAs one after the other)
-        double acc[RMAX];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) acc[r] = y[r];
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j)
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) acc[r] = fma(-x[r][j], uj[j], acc[r]);
-        // (four chains of squares instead of two: 0.349 -> 0.353 us at N = 629, not kept)
+        // (round 3, tried and not kept: columns outside / rows inside, so that the rows' chains of K
+        // dependent FMAs interleave instead of running one after the other as hipcc schedules
+        // this form -- 12 x 4 registers 0.353 -> 0.349 us, but 12 x 8 0.469 -> 0.488 and the
+        // 4-wave form of it 0.628 -> 0.680; four chains of squares instead of two: 0.349 -> 0.353;
+        // a wave-uniform branch for the floor instead of the two selects: 0.349 -> 0.405)
         double part0 = 0.0, part1 = 0.0;
 #pragma unroll
-        for (int r = 0; r < RMAX; r += 2) {
-            part0 = fma(acc[r], acc[r], part0);
-            part1 = fma(acc[r + 1], acc[r + 1], part1);
+        for (int r = 0; r < RMAX; ++r) {
+            double acc = y[r];
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) acc = fma(-x[r][j], uj[j], acc);
+            if (r & 1) part1 = fma(acc, acc, part1);
+            else part0 = fma(acc, acc, part0);
         }
         double rss = wave_sum(part0 + part1);
         if constexpr (MANY) {
@@ -808,8 +806,6 @@ __global__ __launch_bounds__(64 * NWMAX) void gibbs_wave_kernel(GibbsArgs a) {
         }
         // sigma2 | beta = scale_post / g_t, floored at 1e-6            (:50-52)
         const double scale_post = (a.nu0_s20 + rss) * 0.5;
-        // (a wave-uniform branch for the floor, all but never taken, instead of the two selects:
-        // 0.349 -> 0.405 us per iteration at N = 629 -- the scalar unit waits for the compare)
         const bool floor_hit = scale_post < 1e-6 * gam_t;
         sp_eff = floor_hit ? 1e-6 : scale_post;
         g_eff = floor_hit ? 1.0 : gam_t;
@@ -1324,20 +1320,14 @@ __global__ __launch_bounds__(MANY ? 256 : 64) void simplex_wave_kernel(SimplexAr
         for (int j = 0; j < KMAX; ++j) o[j & 3] = fma(uj[j], vtr[j], o[j & 3]);
         const bool neg = model && ((o[0] + o[1]) + (o[2] + o[3]) < 0.0);
         if (!__any(neg)) {
-            // columns outside, rows inside: RMAX independent chains in flight (written row by row,
-            // hipcc reused one accumulator and ran the rows' K dependent FMAs one after the other)
-            double acc[RMAX];
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) acc[r] = y[r];
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j)
-#pragma unroll
-                for (int r = 0; r < RMAX; ++r) acc[r] = fma(-x[r][j], uj[j], acc[r]);
             double part0 = 0.0, part1 = 0.0;
 #pragma unroll
-            for (int r = 0; r < RMAX; r += 2) {
-                part0 = fma(acc[r], acc[r], part0);
-                part1 = fma(acc[r + 1], acc[r + 1], part1);
+            for (int r = 0; r < RMAX; ++r) {
+                double acc = y[r];
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) acc = fma(-x[r][j], uj[j], acc);
+                if (r & 1) part1 = fma(acc, acc, part1);
+                else part0 = fma(acc, acc, part0);
             }
             double rss_prop = wave_sum(part0 + part1);
             if constexpr (MANY) {   // every wave takes this branch together: identical tests
